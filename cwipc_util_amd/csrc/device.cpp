@@ -1,0 +1,303 @@
+// device.cpp -- device selection, per-thread stream context, device memory pool,
+// per-kernel profiling.  No reference counterpart: the reference is CPU-only.
+//
+// Re-entrancy: the reference is called from several threads at once (ctypes
+// releases the GIL; reference python/cwipc/net/source_synchronizer.py:17,184),
+// so every thread gets its own HIP stream, pinned staging buffer and scratch;
+// the pool and the profile table are the only shared state and are locked.
+#include "internal.hpp"
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+namespace cwipc_amd {
+
+namespace {
+
+std::atomic<int> g_device{-2};   // -2: not decided yet
+std::atomic<int> g_device_count{-1};
+thread_local std::string t_last_error;
+
+int device_count() {
+    int n = g_device_count.load();
+    if (n >= 0) return n;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) {
+        (void)hipGetLastError();
+        cnt = 0;
+    }
+    g_device_count.store(cnt);
+    return cnt;
+}
+
+}  // namespace
+
+bool hip_failed(hipError_t err, const char *what, const char *file, int line) {
+    std::string msg = std::string(what) + " failed: " + hipGetErrorString(err) + " (" + file + ":" + std::to_string(line) + ")";
+    t_last_error = msg;
+    cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip", msg);
+    return false;
+}
+
+int current_device() {
+    int d = g_device.load();
+    if (d == -2) {
+        const char *env = getenv("CWIPC_HIP_DEVICE");
+        d = env ? atoi(env) : 0;
+        g_device.store(d);
+    }
+    return d;
+}
+
+bool device_available(const char *who) {
+    if (device_count() > 0 && current_device() < device_count()) return true;
+    std::string msg = "no usable HIP device (hipGetDeviceCount=" + std::to_string(device_count()) +
+                      ", selected " + std::to_string(current_device()) + "); the filters have no CPU fallback";
+    t_last_error = msg;
+    cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, msg);
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// memory pool
+// ---------------------------------------------------------------------------
+namespace {
+
+std::mutex g_pool_mutex;
+std::map<std::pair<int, size_t>, std::vector<void *>> g_pool_free;   // (device, class) -> blocks
+std::unordered_map<void *, std::pair<int, size_t>> g_pool_live;      // block -> (device, class)
+size_t g_pool_bytes = 0;
+
+// Classes: powers of two up to 1 MiB, then eighths of the enclosing power of two (<= 12.5 % slack).
+size_t size_class(size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    size_t p = 256;
+    while (p < bytes && p < (1u << 20)) p <<= 1;
+    if (p >= bytes) return p;
+    p = (size_t)1 << 20;
+    while ((p << 1) <= bytes) p <<= 1;     // p <= bytes < 2p
+    size_t step = p >> 3;
+    return ((bytes + step - 1) / step) * step;
+}
+
+}  // namespace
+
+void *pool_alloc(size_t bytes) {
+    int dev = current_device();
+    size_t cls = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        auto it = g_pool_free.find({dev, cls});
+        if (it != g_pool_free.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_pool_live[p] = {dev, cls};
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e != hipSuccess) {
+        // give cached blocks back and retry once
+        cwipc_hip_pool_trim();
+        e = hipMalloc(&p, cls);
+        if (e != hipSuccess) {
+            hip_failed(e, "hipMalloc", __FILE__, __LINE__);
+            return nullptr;
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool_live[p] = {dev, cls};
+    g_pool_bytes += cls;
+    return p;
+}
+
+void pool_free(void *ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto it = g_pool_live.find(ptr);
+    if (it == g_pool_live.end()) return;
+    g_pool_free[it->second].push_back(ptr);
+    g_pool_live.erase(it);
+}
+
+// ---------------------------------------------------------------------------
+// per-thread context
+// ---------------------------------------------------------------------------
+ThreadCtx &tctx() {
+    static thread_local ThreadCtx ctx;
+    return ctx;
+}
+
+bool ThreadCtx::ensure() {
+    int dev = current_device();
+    CW_HIP_TRY(hipSetDevice(dev));
+    if (stream && device == dev) return true;
+    if (stream) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        if (dev_words) { (void)hipFree(dev_words); dev_words = nullptr; }
+    }
+    device = dev;
+    CW_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!host_words) CW_HIP_TRY(hipHostMalloc((void **)&host_words, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    CW_HIP_TRY(hipMalloc(&dev_words, 64 * sizeof(uint32_t)));
+    return true;
+}
+
+void *ThreadCtx::staging(size_t bytes) {
+    if (bytes <= pinned_bytes) return pinned;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_bytes = 0;
+    size_t want = size_class(bytes);
+    if (hipHostMalloc(&pinned, want, hipHostMallocDefault) != hipSuccess) {
+        hip_failed(hipGetLastError(), "hipHostMalloc(staging)", __FILE__, __LINE__);
+        pinned = nullptr;
+        return nullptr;
+    }
+    pinned_bytes = want;
+    return pinned;
+}
+
+bool ThreadCtx::sync() {
+    CW_HIP_TRY(hipStreamSynchronize(stream));
+    if (profiling_enabled()) profile_collect();
+    return true;
+}
+
+ThreadCtx::~ThreadCtx() {
+    // Runs at thread exit; the runtime may already be shutting down, so errors are ignored.
+    if (stream) (void)hipStreamDestroy(stream);
+    if (pinned) (void)hipHostFree(pinned);
+    if (host_words) (void)hipHostFree(host_words);
+    if (dev_words) (void)hipFree(dev_words);
+}
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+namespace {
+
+std::atomic<int> g_profiling{0};
+struct ProfEntry { std::string name; double ms = 0; long launches = 0; };
+std::mutex g_prof_mutex;
+std::vector<ProfEntry> g_prof;
+
+struct Pending { const char *name; hipEvent_t start, stop; };
+thread_local std::vector<Pending> t_pending;
+thread_local std::vector<hipEvent_t> t_event_cache;
+
+hipEvent_t get_event() {
+    if (!t_event_cache.empty()) {
+        hipEvent_t e = t_event_cache.back();
+        t_event_cache.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+}  // namespace
+
+bool profiling_enabled() { return g_profiling.load(std::memory_order_relaxed) != 0; }
+
+void profile_begin(const char *name, hipStream_t s) {
+    Pending p{name, get_event(), get_event()};
+    (void)hipEventRecord(p.start, s);
+    t_pending.push_back(p);
+}
+
+void profile_end(hipStream_t s) {
+    if (t_pending.empty()) return;
+    (void)hipEventRecord(t_pending.back().stop, s);
+}
+
+void profile_collect() {
+    if (t_pending.empty()) return;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (auto &p : t_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            ProfEntry *e = nullptr;
+            for (auto &x : g_prof) if (x.name == p.name) { e = &x; break; }
+            if (!e) { g_prof.push_back(ProfEntry{p.name, 0, 0}); e = &g_prof.back(); }
+            e->ms += ms;
+            e->launches++;
+        } else {
+            (void)hipGetLastError();
+        }
+        t_event_cache.push_back(p.start);
+        t_event_cache.push_back(p.stop);
+    }
+    t_pending.clear();
+}
+
+}  // namespace cwipc_amd
+
+// ---------------------------------------------------------------------------
+// C extension entry points
+// ---------------------------------------------------------------------------
+using namespace cwipc_amd;
+
+extern "C" int cwipc_hip_device_count(void) { return device_count(); }
+
+extern "C" int cwipc_hip_set_device(int device) {
+    if (device < 0 || device >= device_count()) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip_set_device", "no such device " + std::to_string(device));
+        return -1;
+    }
+    g_device.store(device);
+    return 0;
+}
+
+extern "C" int cwipc_hip_get_device(void) { return current_device(); }
+
+extern "C" const char *cwipc_hip_last_error(void) { return t_last_error.c_str(); }
+
+extern "C" void cwipc_hip_synchronize(void) {
+    ThreadCtx &c = tctx();
+    if (c.stream) c.sync();
+}
+
+extern "C" size_t cwipc_hip_pool_bytes(void) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    return g_pool_bytes;
+}
+
+extern "C" void cwipc_hip_pool_trim(void) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (auto &kv : g_pool_free) {
+        for (void *p : kv.second) {
+            (void)hipFree(p);
+            g_pool_bytes -= kv.first.second;
+        }
+        kv.second.clear();
+    }
+}
+
+extern "C" void cwipc_hip_profile_enable(int on) { g_profiling.store(on ? 1 : 0); }
+
+extern "C" void cwipc_hip_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof.clear();
+}
+
+extern "C" int cwipc_hip_profile_count(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    return (int)g_prof.size();
+}
+
+extern "C" int cwipc_hip_profile_get(int i, const char **name, double *total_ms, long *launches) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (i < 0 || i >= (int)g_prof.size()) return -1;
+    if (name) *name = g_prof[i].name.c_str();
+    if (total_ms) *total_ms = g_prof[i].ms;
+    if (launches) *launches = g_prof[i].launches;
+    return 0;
+}

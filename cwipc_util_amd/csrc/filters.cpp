@@ -1,0 +1,344 @@
+// filters.cpp -- C entry points of the per-point filter hot path and their host
+// orchestration.  Reference: src/cwipc_filters.cpp (wrapping logic, NULL/ERROR
+// conventions, timestamp/cellsize propagation) -- the per-point work itself is in
+// kernels_*.hip.  There is NO CPU fallback: without a usable GPU every filter
+// logs an ERROR and returns NULL.
+#include "internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace cwipc_amd {
+
+namespace {
+
+// Resolve the argument to one of our clouds with device-resident planes.
+// `keep` owns a temporary when the cloud came from another implementation.
+std::shared_ptr<DeviceSoA> device_input(const char *who, cwipc_pointcloud *pc, std::unique_ptr<cwipc_hip_pointcloud> &keep) {
+    cwipc_hip_pointcloud *ours = as_ours(pc);
+    if (!ours) {
+        keep = import_foreign(pc);
+        ours = keep.get();
+        if (!ours) {
+            cwipc_log(CWIPC_LOG_LEVEL_WARNING, who, "cannot read the point data of the argument");
+            return nullptr;
+        }
+    }
+    if (!ours->has_data()) {
+        // the reference sees a NULL pcl cloud here (src/cwipc_filters.cpp:37-40 and alike)
+        cwipc_log(CWIPC_LOG_LEVEL_WARNING, who, "pcl_pointcloud is NULL");
+        return nullptr;
+    }
+    if (!device_available(who)) return nullptr;
+    return ours->device_points();
+}
+
+cwipc_pointcloud *wrap(std::shared_ptr<DeviceSoA> planes, uint64_t timestamp, float cellsize) {
+    if (!planes) return nullptr;
+    auto *rv = new cwipc_hip_pointcloud();
+    rv->adopt_device(planes, timestamp, cellsize);
+    return rv;
+}
+
+}  // namespace
+
+// Stable compaction driver: count -> scan -> (host learns the total, allocates
+// exactly) -> scatter.
+std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p) {
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    size_t n = src.npoints;
+    if (n == 0) return soa_alloc(0);
+    size_t nb = k::compact_blocks(n);
+    uint32_t *counts = (uint32_t *)pool_alloc((nb + 1) * sizeof(uint32_t));
+    if (!counts) return nullptr;
+    uint32_t *total_dev = counts + nb;
+    k::compact_count(src, p, counts, c.stream);
+    k::compact_scan(counts, nb, total_dev, c.stream);
+    bool ok = hipMemcpyAsync(c.host_words, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    ok = c.sync() && ok;
+    std::shared_ptr<DeviceSoA> dst;
+    if (ok) {
+        size_t kept = c.host_words[0];
+        dst = soa_alloc(kept);
+        if (dst && kept) {
+            k::compact_scatter(src, p, counts, *dst, c.stream);
+            if (!c.sync()) dst.reset();
+        }
+    } else {
+        hip_failed(hipGetLastError(), "compaction", __FILE__, __LINE__);
+    }
+    pool_free(counts);
+    return dst;
+}
+
+}  // namespace cwipc_amd
+
+using namespace cwipc_amd;
+
+// ---------------------------------------------------------------------------
+// reference src/cwipc_filters.cpp:281-306
+// ---------------------------------------------------------------------------
+extern "C" cwipc_pointcloud *cwipc_tilefilter(cwipc_pointcloud *pc, int tile) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_tilefilter", pc, keep);
+    if (!src) return nullptr;
+    k::Predicate p{};
+    p.mode = 0;
+    p.tile = tile;
+    return wrap(compact(*src, p), pc->timestamp(), pc->cellsize());
+}
+
+// reference python/cwipc/registration/util.py:98-112 (numpy boolean-mask selection)
+extern "C" cwipc_pointcloud *cwipc_hip_tilefilter_masked(cwipc_pointcloud *pc, int mask) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_tilefilter_masked", pc, keep);
+    if (!src) return nullptr;
+    k::Predicate p{};
+    p.mode = 2;
+    p.tile = mask & 0xff;
+    return wrap(compact(*src, p), pc->timestamp(), pc->cellsize());
+}
+
+// reference src/cwipc_filters.cpp:333-360
+extern "C" cwipc_pointcloud *cwipc_crop(cwipc_pointcloud *pc, float bbox[6]) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_crop", pc, keep);
+    if (!src) return nullptr;
+    k::Predicate p{};
+    p.mode = 1;
+    memcpy(p.bbox, bbox, 6 * sizeof(float));
+    return wrap(compact(*src, p), pc->timestamp(), pc->cellsize());
+}
+
+// reference src/cwipc_filters.cpp:308-331
+extern "C" cwipc_pointcloud *cwipc_tilemap(cwipc_pointcloud *pc, uint8_t map[256]) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_tilemap", pc, keep);
+    if (!src) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_alloc(src->npoints);
+    if (!dst) return nullptr;
+    // the 256-byte table travels through the per-thread pinned words
+    memcpy(c.host_words, map, 256);
+    bool ok = hipMemcpyAsync(c.dev_words, c.host_words, 256, hipMemcpyHostToDevice, c.stream) == hipSuccess;
+    if (ok) k::map_tile(*src, *dst, (const uint8_t *)c.dev_words, c.stream);
+    ok = c.sync() && ok;
+    if (!ok) return nullptr;
+    return wrap(dst, pc->timestamp(), pc->cellsize());
+}
+
+// reference src/cwipc_filters.cpp:362-386
+extern "C" cwipc_pointcloud *cwipc_colormap(cwipc_pointcloud *pc, uint32_t clearBits, uint32_t setBits) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_colormap", pc, keep);
+    if (!src) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_alloc(src->npoints);
+    if (!dst) return nullptr;
+    k::map_color_bits(*src, *dst, clearBits, setBits, c.stream);
+    if (!c.sync()) return nullptr;
+    return wrap(dst, pc->timestamp(), pc->cellsize());
+}
+
+// reference python/cwipc/filters/colorize.py:100-119
+extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid) {
+    if (pc == nullptr || lut == nullptr || valid == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_colorize", pc, keep);
+    if (!src) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_alloc(src->npoints);
+    if (!dst) return nullptr;
+    const int ndoubles = 1025 + 256;
+    double *host_table = (double *)c.staging(ndoubles * sizeof(double));
+    if (!host_table) return nullptr;
+    // the same IEEE double operations Python performs, in the same order
+    for (int t = 0; t < 256; t++)
+        for (int ch = 0; ch < 3; ch++) host_table[t * 3 + ch] = lut[t * 3 + ch] * weight;
+    for (int v = 0; v < 256; v++) host_table[768 + v] = v / 255.0;
+    host_table[1024] = 1 - weight;
+    for (int t = 0; t < 256; t++) host_table[1025 + t] = valid[t] ? 1.0 : 0.0;
+    double *dev_table = (double *)pool_alloc(ndoubles * sizeof(double));
+    if (!dev_table) return nullptr;
+    bool ok = hipMemcpyAsync(dev_table, host_table, ndoubles * sizeof(double), hipMemcpyHostToDevice, c.stream) == hipSuccess;
+    if (ok) k::map_colorize(*src, *dst, dev_table, c.stream);
+    ok = c.sync() && ok;
+    pool_free(dev_table);
+    if (!ok) return nullptr;
+    return wrap(dst, pc->timestamp(), pc->cellsize());
+}
+
+// reference src/cwipc_filters.cpp:388-418; n-ary form = left fold (python/cwipc/util.py:1330-1332)
+extern "C" cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int npc) {
+    if (pcs == nullptr || npc <= 0) return nullptr;
+    for (int i = 0; i < npc; i++) if (pcs[i] == nullptr) return nullptr;
+    std::vector<std::unique_ptr<cwipc_hip_pointcloud>> keep(npc);
+    std::vector<std::shared_ptr<DeviceSoA>> src(npc);
+    size_t total = 0;
+    for (int i = 0; i < npc; i++) {
+        src[i] = device_input("cwipc_join", pcs[i], keep[i]);
+        if (!src[i]) {
+            cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_join", "some pcl_pointcloud is NULL");
+            return nullptr;
+        }
+        total += src[i]->npoints;
+    }
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_alloc(total);
+    if (!dst) return nullptr;
+    size_t off = 0;
+    for (int i = 0; i < npc; i++) {
+        k::JoinPart part{src[i]->x(), src[i]->y(), src[i]->z(), src[i]->rgbt(), src[i]->npoints, off};
+        k::join_copy(part, *dst, c.stream);
+        off += src[i]->npoints;
+    }
+    if (!c.sync()) return nullptr;
+    uint64_t ts = pcs[0]->timestamp();
+    float cellsize = pcs[0]->cellsize();
+    for (int i = 1; i < npc; i++) {
+        ts = std::min(ts, pcs[i]->timestamp());
+        cellsize = std::min(cellsize, pcs[i]->cellsize());
+    }
+    return wrap(dst, ts, cellsize);
+}
+
+extern "C" cwipc_pointcloud *cwipc_join(cwipc_pointcloud *pc1, cwipc_pointcloud *pc2) {
+    if (pc1 == nullptr || pc2 == nullptr) return nullptr;
+    cwipc_pointcloud *both[2] = {pc1, pc2};
+    return cwipc_hip_join_multi(both, 2);
+}
+
+// ---------------------------------------------------------------------------
+// reference src/cwipc_filters.cpp:30-172
+// ---------------------------------------------------------------------------
+extern "C" cwipc_pointcloud *cwipc_downsample(cwipc_pointcloud *pc, float cellsize) {
+    bool leaf_split = true;
+    const char *who = "cwipc_downsample";
+    if (cellsize < 0) {          // :90-92 -> cwipc_downsample_voxelgrid(pc, -cellsize)
+        cellsize = -cellsize;
+        leaf_split = false;
+        who = "cwipc_downsample_voxelgrid";
+    }
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input(who, pc, keep);
+    if (!src) return nullptr;
+    float oldcellsize = pc->cellsize();   // :42-46, :103-107
+    if (oldcellsize >= cellsize) cellsize = oldcellsize;
+    if (src->npoints == 0) {
+        if (leaf_split) return wrap(soa_alloc(0), pc->timestamp(), cellsize);   // zero leaves -> empty cloud
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "VoxelGrid filter produced empty pointcloud");   // :58-62
+        return nullptr;
+    }
+    int err = 0;
+    auto dst = voxel_downsample(*src, cellsize, leaf_split, &err);
+    if (!dst) return nullptr;
+    return wrap(dst, pc->timestamp(), cellsize);
+}
+
+// ---------------------------------------------------------------------------
+// reference src/cwipc_filters.cpp:181-278
+// ---------------------------------------------------------------------------
+namespace {
+
+// The inner overload (:181-211): SOR over one cloud's planes.
+std::shared_ptr<DeviceSoA> sor_once(const DeviceSoA &src, int k, float stddev_mul) {
+    if (src.npoints == 0) return soa_alloc(0);
+    float *dist = (float *)pool_alloc(src.npoints * sizeof(float));
+    if (!dist) return nullptr;
+    std::shared_ptr<DeviceSoA> out;
+    double thr = 0;
+    if (sor_mean_distances(src, k, dist) && sor_threshold(dist, src.npoints, stddev_mul, &thr)) out = sor_select(src, dist, thr);
+    pool_free(dist);
+    return out;
+}
+
+}  // namespace
+
+extern "C" cwipc_pointcloud *cwipc_remove_outliers(cwipc_pointcloud *pc, int kNeighbors, float stddevMulThresh, bool perTile) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_remove_outliers", pc, keep);
+    if (!src) return nullptr;
+    if (!perTile) {   // :262-268
+        return wrap(sor_once(*src, kNeighbors, stddevMulThresh), pc->timestamp(), pc->cellsize());
+    }
+    // :238-261 -- distinct tiles in first-appearance order.  The tile plane is one
+    // byte per point: fetch it and scan on the host (N bytes over PCIe is small
+    // next to the k-NN work that follows).
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    size_t n = src->npoints;
+    std::vector<int> tiles;
+    if (n) {
+        uint32_t *stage = (uint32_t *)c.staging(n * sizeof(uint32_t));
+        if (!stage) return nullptr;
+        bool ok = hipMemcpyAsync(stage, src->rgbt(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+        ok = c.sync() && ok;
+        if (!ok) return nullptr;
+        bool seen[256] = {false};
+        for (size_t i = 0; i < n && tiles.size() < 256; i++) {
+            int t = (int)(stage[i] >> 24);
+            if (!seen[t]) { seen[t] = true; tiles.push_back(t); }
+        }
+    }
+    std::vector<std::shared_ptr<DeviceSoA>> parts;
+    size_t total = 0;
+    for (int tile : tiles) {
+        k::Predicate p{};
+        p.mode = 0;          // cwipc_tilefilter semantics, including tile 0 = wildcard (:252, :296)
+        p.tile = tile;
+        auto sub = compact(*src, p);
+        if (!sub) return nullptr;
+        auto cleaned = sor_once(*sub, kNeighbors, stddevMulThresh);
+        if (!cleaned) return nullptr;
+        total += cleaned->npoints;
+        parts.push_back(cleaned);
+    }
+    auto dst = soa_alloc(total);
+    if (!dst) return nullptr;
+    size_t off = 0;
+    for (auto &part : parts) {
+        k::JoinPart jp{part->x(), part->y(), part->z(), part->rgbt(), part->npoints, off};
+        k::join_copy(jp, *dst, c.stream);
+        off += part->npoints;
+    }
+    if (!c.sync()) return nullptr;
+    return wrap(dst, pc->timestamp(), pc->cellsize());
+}
+
+extern "C" int cwipc_hip_knn_mean_dist(cwipc_pointcloud *pc, int kNeighbors, float *mean_dist, size_t cap, double *threshold, float stddevMulThresh) {
+    if (pc == nullptr) return -1;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_knn_mean_dist", pc, keep);
+    if (!src) return -1;
+    size_t n = src->npoints;
+    if (cap < n) return -1;
+    if (n == 0) return 0;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return -1;
+    float *dist = (float *)pool_alloc(n * sizeof(float));
+    if (!dist) return -1;
+    bool ok = sor_mean_distances(*src, kNeighbors, dist);
+    double thr = 0;
+    if (ok && threshold) ok = sor_threshold(dist, n, stddevMulThresh, &thr);
+    if (ok) {
+        void *stage = c.staging(n * sizeof(float));
+        ok = stage && hipMemcpyAsync(stage, dist, n * sizeof(float), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+        ok = c.sync() && ok;
+        if (ok) memcpy(mean_dist, stage, n * sizeof(float));
+    }
+    pool_free(dist);
+    if (ok && threshold) *threshold = thr;
+    return ok ? 0 : -1;
+}

@@ -1,0 +1,242 @@
+// internal.hpp -- shared declarations of the MI355X libcwipc_util implementation.
+//
+// Layering:
+//   logging.cpp     cwipc_log & friends            (reference src/logging.cpp)
+//   device.cpp      device selection, per-thread stream, memory pool, profiling
+//   pointcloud.cpp  cwipc_hip_pointcloud container, C accessors, packet / dump I/O
+//   synthetic.cpp   cwipc_synthetic source          (reference src/cwipc_synthetic.cpp)
+//   stubs.cpp       out-of-scope constructors that fail loudly
+//   filters.cpp     C entry points of the hot path, host orchestration
+//   kernels_*.hip   the HIP kernels (gfx950)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstddef>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "cwipc_util/api.h"
+#include "cwipc_util_amd/hip_ext.h"
+
+// ---------------------------------------------------------------------------
+// logging (reference include/cwipc_util/internal/logging.hpp:11-21)
+// ---------------------------------------------------------------------------
+extern "C" {
+_CWIPC_UTIL_EXPORT void cwipc_log(cwipc_log_level level, std::string module, std::string message);
+_CWIPC_UTIL_EXPORT void cwipc_log_set_errorbuf(char **errorbuf);
+_CWIPC_UTIL_EXPORT cwipc_log_level cwipc_log_get_level();
+}
+
+namespace cwipc_amd {
+
+// Reject a constructor call whose apiVersion is outside the accepted window
+// (pattern of reference src/cwipc_util.cpp:663-670).  Returns true if rejected.
+bool api_version_rejected(const char *fname, uint64_t apiVersion, char **errorMessage);
+
+// ---------------------------------------------------------------------------
+// device context
+// ---------------------------------------------------------------------------
+
+// Record a HIP failure: thread-local text + cwipc_log(ERROR).  Returns false.
+bool hip_failed(hipError_t err, const char *what, const char *file, int line);
+#define CW_HIP_OK(expr) ((expr) == hipSuccess ? true : ::cwipc_amd::hip_failed(hipGetLastError(), #expr, __FILE__, __LINE__))
+#define CW_HIP_TRY(expr)                                                            \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            ::cwipc_amd::hip_failed(_e, #expr, __FILE__, __LINE__);                 \
+            return false;                                                           \
+        }                                                                           \
+    } while (0)
+
+// True when a usable GPU exists; logs an ERROR (once per call) otherwise.  The
+// product has NO CPU fallback for the filters: callers return NULL when false.
+bool device_available(const char *who);
+int current_device();
+
+// Device memory pool: size-classed free lists, never shrinks unless trimmed.
+// All library calls synchronise their stream before returning, so a block can
+// be reused by any stream as soon as it has been released.
+void *pool_alloc(size_t bytes);
+void pool_free(void *ptr);
+
+struct PoolDeleter {
+    void operator()(void *p) const { pool_free(p); }
+};
+
+// Per-thread execution context: one non-blocking stream, pinned staging, scratch.
+struct ThreadCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *pinned = nullptr;       // staging for H2D/D2H of AoS points
+    size_t pinned_bytes = 0;
+    uint32_t *host_words = nullptr;   // 64 pinned 32-bit words for small read-backs
+    void *dev_words = nullptr;        // 64 device words
+    bool ensure();                    // create the stream etc. for the current device
+    void *staging(size_t bytes);      // pinned buffer of at least `bytes`
+    bool sync();
+    ~ThreadCtx();
+};
+ThreadCtx &tctx();
+
+// Profiling: kernels are launched through CW_LAUNCH so that per-kernel device
+// time can be collected with hipEvents on the launching stream.
+void profile_begin(const char *name, hipStream_t s);
+void profile_end(hipStream_t s);
+void profile_collect();   // after a stream sync: fold finished event pairs into totals
+bool profiling_enabled();
+
+#define CW_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                               \
+    do {                                                                                       \
+        if (::cwipc_amd::profiling_enabled()) ::cwipc_amd::profile_begin(name, stream);        \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                   \
+        if (::cwipc_amd::profiling_enabled()) ::cwipc_amd::profile_end(stream);                \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// point storage
+// ---------------------------------------------------------------------------
+
+// Device representation: four planes in one pool block, each plane `stride`
+// elements long (stride = npoints rounded up to 64 so every plane starts on a
+// 256-byte boundary).  rgbt = r | g<<8 | b<<16 | tile<<24, i.e. the last four
+// bytes of a cwipc_point read as one little-endian word.
+struct DeviceSoA {
+    void *base = nullptr;
+    size_t npoints = 0;
+    size_t stride = 0;
+    int device = 0;
+    float *x() const { return (float *)base; }
+    float *y() const { return (float *)base + stride; }
+    float *z() const { return (float *)base + 2 * stride; }
+    uint32_t *rgbt() const { return (uint32_t *)base + 3 * stride; }
+    ~DeviceSoA() { if (base) pool_free(base); }
+};
+std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints);
+
+// Host representation: malloc'd AoS exactly as handed in through the C-ABI.
+struct HostAoS {
+    cwipc_point *points = nullptr;
+    size_t npoints = 0;
+    ~HostAoS() { ::free(points); }
+};
+
+// The cwipc_pointcloud implementation.  Either representation may be missing;
+// the other one is materialised on demand (device: filters; host: accessors).
+class cwipc_hip_pointcloud : public cwipc_pointcloud {
+public:
+    cwipc_hip_pointcloud();
+    ~cwipc_hip_pointcloud() override;
+
+    // cwipc_pointcloud interface
+    void free() override;
+    cwipc_pointcloud *_shallowcopy() override;
+    uint64_t timestamp() override;
+    float cellsize() override;
+    void _set_cellsize(float cellsize) override;
+    void _set_timestamp(uint64_t timestamp) override;
+    int count() override;
+    size_t get_uncompressed_size() override;
+    int copy_uncompressed(struct cwipc_point *pointbuf, size_t size) override;
+    size_t copy_packet(uint8_t *packet, size_t size) override;
+    cwipc_pcl_pointcloud access_pcl_pointcloud() override;
+    cwipc_metadata *access_metadata() override;
+
+    // construction helpers
+    int from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp);
+    void adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize);
+
+    // residency
+    std::shared_ptr<DeviceSoA> device_points();   // uploads if needed; nullptr on failure
+    std::shared_ptr<HostAoS> host_points();       // downloads if needed; nullptr on failure
+    bool has_device() const { return (bool)m_dev; }
+    bool has_host() const { return (bool)m_host; }
+    bool drop_host();
+    size_t npoints() const { return m_npoints; }
+    bool has_data() const { return m_has_data; }
+
+private:
+    int copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact);
+    std::mutex m_lock;
+    uint64_t m_timestamp = 0;
+    float m_cellsize = 0;
+    size_t m_npoints = 0;
+    bool m_has_data = false;      // counts towards cwipc_dangling_allocations
+    bool m_exact_size = false;    // from_points flavour: copy_uncompressed wants size == exact
+    std::shared_ptr<HostAoS> m_host;
+    std::shared_ptr<DeviceSoA> m_dev;
+    cwipc_metadata *m_metadata = nullptr;
+};
+
+// A cwipc_pointcloud that is not ours (another library's implementation) is
+// read through its virtual interface into a temporary of ours.
+std::unique_ptr<cwipc_hip_pointcloud> import_foreign(cwipc_pointcloud *pc);
+cwipc_hip_pointcloud *as_ours(cwipc_pointcloud *pc);
+
+void count_alloc();
+void count_dealloc();
+
+// ---------------------------------------------------------------------------
+// kernel launchers (kernels_basic.hip, kernels_voxel.hip, kernels_sor.hip)
+// All work on the calling thread's stream; none synchronises unless stated.
+// ---------------------------------------------------------------------------
+namespace k {
+
+// AoS (device) <-> SoA
+void aos_to_soa(const cwipc_point *aos, const DeviceSoA &dst, size_t n, hipStream_t s);
+void soa_to_aos(const DeviceSoA &src, cwipc_point *aos, size_t n, hipStream_t s);
+
+// Stable compaction.  mode 0: tile == 0 || tile == pt.tile ; mode 1: half-open bbox ;
+// mode 2: (pt.tile & tile) != 0 ; mode 3: !(dist[i] > thr)  (outlier removal).
+struct Predicate {
+    int mode;
+    int tile;
+    float bbox[6];
+    const float *dist;
+    double thr;
+};
+// Pass 1: per-block keep counts into block_counts[nblocks]; returns nblocks through the argument.
+size_t compact_blocks(size_t n);
+void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, hipStream_t s);
+// Exclusive scan of block_counts in place; total written to *total_dev.
+void compact_scan(uint32_t *block_counts, size_t nblocks, uint32_t *total_dev, hipStream_t s);
+// Pass 2: scatter kept points to dst in input order.
+void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s);
+
+// Per-point maps on the rgbt word (x,y,z copied).
+void map_tile(const DeviceSoA &src, const DeviceSoA &dst, const uint8_t *dev_map256, hipStream_t s);
+void map_color_bits(const DeviceSoA &src, const DeviceSoA &dst, uint32_t clearBits, uint32_t setBits, hipStream_t s);
+// colorize: dev_table = 256 entries of {double cw[3]; double valid;} followed by 256 doubles old/255.0, then (1-w).
+void map_colorize(const DeviceSoA &src, const DeviceSoA &dst, const double *dev_table, hipStream_t s);
+
+// Concatenate nsrc clouds (device array of plane pointers) into dst.
+struct JoinPart {
+    const float *x, *y, *z;
+    const uint32_t *rgbt;
+    size_t n;
+    size_t dst_offset;
+};
+void join_copy(const JoinPart &part, const DeviceSoA &dst, hipStream_t s);
+
+}  // namespace k
+
+// Voxel-grid downsample (kernels_voxel.hip).  Returns the new cloud's planes or
+// nullptr (error already logged).  leaf_split = positive-cellsize path.
+std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize, bool leaf_split, int *error_code);
+
+// Statistical outlier removal (kernels_sor.hip).  Computes d_i into dev_dist
+// (n floats, device), returns false on failure.
+bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist);
+// mean/stddev threshold from d_i exactly as pcl::StatisticalOutlierRemoval; result in *thr.
+bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *thr);
+// Stable compaction of points with !(d_i > thr).
+std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr);
+
+// Generic stable compaction driver used by tilefilter / crop / masked filter.
+std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p);
+
+}  // namespace cwipc_amd

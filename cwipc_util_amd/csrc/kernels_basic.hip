@@ -1,0 +1,398 @@
+// kernels_basic.hip -- gfx950 kernels for the exact per-point filters and the
+// AoS <-> SoA copy path.  All of them are HBM-bound byte/integer work: the
+// design rules are coalesced 4/16-byte accesses on the SoA planes, wave64
+// ballot/prefix for stable compaction, and enough workgroups (>> 256) to fill
+// the 8 XCDs.  No MFMA: nothing here is a contraction.
+//
+// Reference semantics (bit-exact, including output order):
+//   tilefilter  src/cwipc_filters.cpp:295-299      crop      :347-354
+//   tilemap     src/cwipc_filters.cpp:322-325      colormap  :376-380
+//   join        src/cwipc_filters.cpp:403-409      colorize  python/cwipc/filters/colorize.py:100-119
+#include "internal.hpp"
+
+namespace cwipc_amd {
+namespace k {
+
+static constexpr int BLOCK = 256;
+static constexpr int WAVES = BLOCK / 64;
+
+// ---------------------------------------------------------------------------
+// AoS <-> SoA
+// ---------------------------------------------------------------------------
+// One 16-byte record per lane: a wave reads/writes 1 KiB contiguous on the AoS
+// side and four 256-byte runs on the plane side.
+__global__ void __launch_bounds__(BLOCK) aos_to_soa_kernel(const uint4 *__restrict__ aos, float *__restrict__ x, float *__restrict__ y,
+                                                          float *__restrict__ z, uint32_t *__restrict__ rgbt, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * BLOCK;
+    for (; i < n; i += stride) {
+        uint4 p = aos[i];
+        x[i] = __uint_as_float(p.x);
+        y[i] = __uint_as_float(p.y);
+        z[i] = __uint_as_float(p.z);
+        rgbt[i] = p.w;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) soa_to_aos_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                          const uint32_t *__restrict__ rgbt, uint4 *__restrict__ aos, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * BLOCK;
+    for (; i < n; i += stride) {
+        uint4 p;
+        p.x = __float_as_uint(x[i]);
+        p.y = __float_as_uint(y[i]);
+        p.z = __float_as_uint(z[i]);
+        p.w = rgbt[i];
+        aos[i] = p;
+    }
+}
+
+static inline unsigned grid_for(size_t n, size_t per_block) {
+    size_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;   // grid-stride beyond 32 blocks per CU
+    return (unsigned)g;
+}
+
+void aos_to_soa(const cwipc_point *aos, const DeviceSoA &dst, size_t n, hipStream_t s) {
+    if (!n) return;
+    CW_LAUNCH("aos_to_soa", aos_to_soa_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, (const uint4 *)aos, dst.x(), dst.y(), dst.z(), dst.rgbt(), n);
+}
+
+void soa_to_aos(const DeviceSoA &src, cwipc_point *aos, size_t n, hipStream_t s) {
+    if (!n) return;
+    CW_LAUNCH("soa_to_aos", soa_to_aos_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, src.x(), src.y(), src.z(), src.rgbt(), (uint4 *)aos, n);
+}
+
+// ---------------------------------------------------------------------------
+// Stable compaction (tilefilter / crop / masked tilefilter)
+// ---------------------------------------------------------------------------
+// A workgroup owns TILE consecutive points.  Pass 1 counts the kept points per
+// workgroup, a one-workgroup scan turns counts into offsets, pass 2 re-evaluates
+// the predicate and writes every kept point at offset + rank, where rank comes
+// from a wave64 ballot/popcount prefix -- so output order == input order.
+static constexpr int ITEMS = 4;                         // points per lane and step (one dwordx4 per plane)
+static constexpr int STEPS = 4;                         // steps per workgroup
+static constexpr int TILE = BLOCK * ITEMS * STEPS;      // 4096 points per workgroup
+
+size_t compact_blocks(size_t n) { return (n + TILE - 1) / TILE; }
+
+struct PredArgs {
+    int mode;
+    int tile;
+    float b0, b1, b2, b3, b4, b5;
+    const float *dist;
+    double thr;
+};
+
+__device__ __forceinline__ bool keep_point(const PredArgs &p, float x, float y, float z, uint32_t w, size_t idx) {
+    int t = (int)(w >> 24);
+    if (p.mode == 0) return p.tile == 0 || p.tile == t;
+    if (p.mode == 2) return (t & p.tile) != 0;
+    if (p.mode == 3) return !((double)p.dist[idx] > p.thr);   // fp32 d_i widened for the f64 compare
+    return p.b0 <= x && x < p.b1 && p.b2 <= y && y < p.b3 && p.b4 <= z && z < p.b5;
+}
+
+// Loads ITEMS consecutive points of one lane; out-of-range items report keep = false.
+template <bool NEED_XYZ>
+__device__ __forceinline__ unsigned lane_mask(const PredArgs &p, const float *__restrict__ x, const float *__restrict__ y,
+                                              const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t base, size_t n,
+                                              float4 &vx, float4 &vy, float4 &vz, uint4 &vw) {
+    unsigned m = 0;
+    if (base + ITEMS <= n) {
+        vw = *(const uint4 *)(rgbt + base);
+        if (NEED_XYZ) {
+            vx = *(const float4 *)(x + base);
+            vy = *(const float4 *)(y + base);
+            vz = *(const float4 *)(z + base);
+        }
+        m |= keep_point(p, vx.x, vy.x, vz.x, vw.x, base) ? 1u : 0u;
+        m |= keep_point(p, vx.y, vy.y, vz.y, vw.y, base + 1) ? 2u : 0u;
+        m |= keep_point(p, vx.z, vy.z, vz.z, vw.z, base + 2) ? 4u : 0u;
+        m |= keep_point(p, vx.w, vy.w, vz.w, vw.w, base + 3) ? 8u : 0u;
+    } else if (base < n) {
+        float ax[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0}, az[4] = {0, 0, 0, 0};
+        uint32_t aw[4] = {0, 0, 0, 0};
+        for (int j = 0; j < ITEMS; j++) {
+            if (base + j < n) {
+                aw[j] = rgbt[base + j];
+                if (NEED_XYZ) { ax[j] = x[base + j]; ay[j] = y[base + j]; az[j] = z[base + j]; }
+                if (keep_point(p, ax[j], ay[j], az[j], aw[j], base + j)) m |= 1u << j;
+            }
+        }
+        vx = make_float4(ax[0], ax[1], ax[2], ax[3]);
+        vy = make_float4(ay[0], ay[1], ay[2], ay[3]);
+        vz = make_float4(az[0], az[1], az[2], az[3]);
+        vw = make_uint4(aw[0], aw[1], aw[2], aw[3]);
+    }
+    return m;
+}
+
+__global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
+                                                             uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t wave_sum[WAVES];
+    size_t tile0 = (size_t)blockIdx.x * TILE;
+    uint32_t cnt = 0;
+    float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
+    uint4 vw;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
+        unsigned m = (p.mode == 1) ? lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
+                                   : lane_mask<false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
+        cnt += __popc(m);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < WAVES; w++) t += wave_sum[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+// Exclusive scan of up to millions of block counts by ONE workgroup of 1024 lanes
+// (the count array is tiny: N/4096 entries).
+__global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict__ counts, size_t nblocks, uint32_t *__restrict__ total) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t base = 0; base < nblocks; base += 1024) {
+        size_t i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? counts[i] : 0;
+        uint32_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t wave_base = 0;
+        for (int w = 0; w < wave; w++) wave_base += wave_tot[w];
+        uint32_t c = carry;
+        if (i < nblocks) counts[i] = c + wave_base + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wave_base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
+                                                               const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
+                                                               const uint32_t *__restrict__ block_offsets, float *__restrict__ ox,
+                                                               float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
+    __shared__ uint32_t wave_sum[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t tile0 = (size_t)blockIdx.x * TILE;
+    size_t out = block_offsets[blockIdx.x];
+#pragma unroll 1
+    for (int s = 0; s < STEPS; s++) {
+        size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
+        float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
+        uint4 vw = make_uint4(0, 0, 0, 0);
+        // the scatter needs all four planes of the kept points
+        unsigned m = lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
+        uint32_t c = __popc(m);
+        // wave-inclusive prefix of the per-lane keep counts
+        uint32_t inc = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_sum[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+        for (int w = 0; w < WAVES; w++) {
+            uint32_t t = wave_sum[w];
+            if (w < wave) wbase += t;
+            total += t;
+        }
+        size_t pos = out + wbase + inc - c;
+        const float ax[4] = {vx.x, vx.y, vx.z, vx.w}, ay[4] = {vy.x, vy.y, vy.z, vy.w}, az[4] = {vz.x, vz.y, vz.z, vz.w};
+        const uint32_t aw[4] = {vw.x, vw.y, vw.z, vw.w};
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            if (m & (1u << j)) {
+                ox[pos] = ax[j];
+                oy[pos] = ay[j];
+                oz[pos] = az[j];
+                ow[pos] = aw[j];
+                pos++;
+            }
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
+static PredArgs to_args(const Predicate &p) {
+    PredArgs a;
+    a.mode = p.mode;
+    a.tile = p.tile;
+    a.b0 = p.bbox[0]; a.b1 = p.bbox[1]; a.b2 = p.bbox[2];
+    a.b3 = p.bbox[3]; a.b4 = p.bbox[4]; a.b5 = p.bbox[5];
+    a.dist = p.dist;
+    a.thr = p.thr;
+    return a;
+}
+
+void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, hipStream_t s) {
+    size_t nb = compact_blocks(src.npoints);
+    if (!nb) return;
+    CW_LAUNCH("compact_count", compact_count_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(), src.rgbt(),
+              src.npoints, block_counts);
+}
+
+void compact_scan(uint32_t *block_counts, size_t nblocks, uint32_t *total_dev, hipStream_t s) {
+    CW_LAUNCH("compact_scan", compact_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_dev);
+}
+
+void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s) {
+    size_t nb = compact_blocks(src.npoints);
+    if (!nb) return;
+    CW_LAUNCH("compact_scatter", compact_scatter_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+              src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt());
+}
+
+// ---------------------------------------------------------------------------
+// Per-point maps on the packed colour/tile word
+// ---------------------------------------------------------------------------
+enum { MAP_TILE = 0, MAP_BITS = 1, MAP_COLORIZE = 2 };
+
+struct MapArgs {
+    uint32_t clear_mask;   // MAP_BITS: word &= ~clear ; word |= set   (already in rgbt byte order)
+    uint32_t set_mask;
+};
+
+// Layout of the colorize table in device memory (doubles):
+//   [0, 768)    cw[t][c]  = colour[t][c] * weight        (host product, Python float semantics)
+//   [768, 1024) oldf[v]   = v / 255.0
+//   [1024]      omw       = 1 - weight
+//   [1025,1281) valid[t]  (non-zero = the colour map has an entry for tile t)
+static constexpr int COLORIZE_DOUBLES = 1025 + 256;
+
+template <int KIND>
+__global__ void __launch_bounds__(BLOCK) map_kernel(MapArgs a, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                   const uint32_t *__restrict__ rgbt, float *__restrict__ ox, float *__restrict__ oy,
+                                                   float *__restrict__ oz, uint32_t *__restrict__ ow, size_t n, const void *__restrict__ table) {
+    __shared__ double lut[KIND == MAP_COLORIZE ? COLORIZE_DOUBLES : 1];
+    __shared__ uint8_t tmap[KIND == MAP_TILE ? 256 : 1];
+    if (KIND == MAP_TILE) {
+        tmap[threadIdx.x] = ((const uint8_t *)table)[threadIdx.x];   // BLOCK == 256
+        __syncthreads();
+    }
+    if (KIND == MAP_COLORIZE) {
+        for (int i = threadIdx.x; i < COLORIZE_DOUBLES; i += BLOCK) lut[i] = ((const double *)table)[i];
+        __syncthreads();
+    }
+    const size_t nvec = n / 4;
+    size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t v = (size_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec + 1; v += stride) {
+        uint32_t w[4];
+        int cnt = 4;
+        if (v < nvec) {
+            uint4 t = ((const uint4 *)rgbt)[v];
+            w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+            ((float4 *)ox)[v] = ((const float4 *)x)[v];
+            ((float4 *)oy)[v] = ((const float4 *)y)[v];
+            ((float4 *)oz)[v] = ((const float4 *)z)[v];
+        } else {
+            cnt = (int)(n - nvec * 4);   // ragged tail, handled by one lane
+            for (int j = 0; j < cnt; j++) {
+                size_t i = nvec * 4 + j;
+                w[j] = rgbt[i];
+                ox[i] = x[i]; oy[i] = y[i]; oz[i] = z[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j >= cnt) break;
+            uint32_t word = w[j];
+            if (KIND == MAP_TILE) {
+                word = (word & 0x00ffffffu) | ((uint32_t)tmap[word >> 24] << 24);
+            } else if (KIND == MAP_BITS) {
+                word = (word & ~a.clear_mask) | a.set_mask;
+            } else {
+                uint32_t t = word >> 24;
+                if (lut[1025 + t] != 0.0) {
+                    const double omw = lut[1024];
+                    uint32_t outw = word & 0xff000000u;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        uint32_t old = (word >> (8 * c)) & 0xffu;
+                        // new = colour*w + (old/255.0)*(1-w), then int(new*255): separately rounded f64 ops
+                        double blended = __dadd_rn(lut[t * 3 + c], __dmul_rn(lut[768 + old], omw));
+                        long long q = (long long)__dmul_rn(blended, 255.0);
+                        outw |= ((uint32_t)q & 0xffu) << (8 * c);
+                    }
+                    word = outw;
+                }
+            }
+            w[j] = word;
+        }
+        if (v < nvec) {
+            ((uint4 *)ow)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int j = 0; j < cnt; j++) ow[nvec * 4 + j] = w[j];
+        }
+    }
+}
+
+template <int KIND>
+static void launch_map(const char *name, const DeviceSoA &src, const DeviceSoA &dst, MapArgs a, const void *table, hipStream_t s) {
+    size_t n = src.npoints;
+    if (!n) return;
+    CW_LAUNCH(name, (map_kernel<KIND>), dim3(grid_for(n / 4 + 1, BLOCK)), dim3(BLOCK), 0, s, a, src.x(), src.y(), src.z(), src.rgbt(), dst.x(),
+              dst.y(), dst.z(), dst.rgbt(), n, table);
+}
+
+void map_tile(const DeviceSoA &src, const DeviceSoA &dst, const uint8_t *dev_map256, hipStream_t s) {
+    launch_map<MAP_TILE>("map_tile", src, dst, MapArgs{0, 0}, dev_map256, s);
+}
+
+// The reference masks PCL's rgba word (a<<24 | r<<16 | g<<8 | b, reference
+// include/cwipc_util/api_pcl.h:20-70); the planes hold r | g<<8 | b<<16 | tile<<24,
+// so the r and b bytes of both masks are swapped once on the host.
+static inline uint32_t swap_rb(uint32_t m) { return (m & 0xff00ff00u) | ((m & 0xffu) << 16) | ((m >> 16) & 0xffu); }
+
+void map_color_bits(const DeviceSoA &src, const DeviceSoA &dst, uint32_t clearBits, uint32_t setBits, hipStream_t s) {
+    launch_map<MAP_BITS>("map_color_bits", src, dst, MapArgs{swap_rb(clearBits), swap_rb(setBits)}, nullptr, s);
+}
+
+void map_colorize(const DeviceSoA &src, const DeviceSoA &dst, const double *dev_table, hipStream_t s) {
+    launch_map<MAP_COLORIZE>("map_colorize", src, dst, MapArgs{0, 0}, dev_table, s);
+}
+
+// ---------------------------------------------------------------------------
+// join: plane-wise concatenation
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) join_copy_kernel(JoinPart part, float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
+                                                         uint32_t *__restrict__ ow) {
+    // blockIdx.y selects the plane; destination offsets are arbitrary, so 4-byte accesses.
+    const uint32_t *src;
+    uint32_t *dst;
+    switch (blockIdx.y) {
+    case 0: src = (const uint32_t *)part.x; dst = (uint32_t *)ox; break;
+    case 1: src = (const uint32_t *)part.y; dst = (uint32_t *)oy; break;
+    case 2: src = (const uint32_t *)part.z; dst = (uint32_t *)oz; break;
+    default: src = part.rgbt; dst = ow; break;
+    }
+    dst += part.dst_offset;
+    size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < part.n; i += stride) dst[i] = src[i];
+}
+
+void join_copy(const JoinPart &part, const DeviceSoA &dst, hipStream_t s) {
+    if (!part.n) return;
+    unsigned gx = grid_for(part.n, BLOCK * 4);
+    CW_LAUNCH("join_copy", join_copy_kernel, dim3(gx, 4), dim3(BLOCK), 0, s, part, dst.x(), dst.y(), dst.z(), dst.rgbt());
+}
+
+}  // namespace k
+}  // namespace cwipc_amd

@@ -1,0 +1,364 @@
+// kernels_sor.hip -- statistical outlier removal on gfx950.
+//
+// Reference: cwipc_remove_outliers, src/cwipc_filters.cpp:181-278; the filter
+// itself is pcl::StatisticalOutlierRemoval [PCL upstream], restated in
+// oracle/cwipc_oracle.c (sor_filter):
+//   d_i  = float( sum_{j=1..k} sqrtf(dist2_j) / k )   exact k+1 nearest (self = j 0),
+//          dist2 in fp32 as FLANN's L2_Simple ((dx*dx + dy*dy) + dz*dz), ascending, sum in f64
+//   mean / variance over all d_i in f64 (squares formed in fp32), threshold = mean + mul*stddev
+//   keep point i iff !(d_i > threshold), input order preserved.
+//
+// The k nearest distances of a point are a well-defined multiset, so d_i does not
+// depend on how the neighbour search is organised.  Here: points are bucketed
+// into a uniform grid (counting sort), each lane searches growing cubic shells
+// of cells around its point and keeps the k+1 smallest distances in LDS; a shell
+// radius r proves exactness once the (k+1)-th distance is <= r*h.
+#include "internal.hpp"
+
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include <cfloat>
+#include <cmath>
+
+namespace cwipc_amd {
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr size_t MAX_CELLS = (size_t)1 << 24;
+
+struct Grid {
+    float mn[3];
+    int dim[3];
+    double h;
+    double inv_h;
+};
+
+__device__ __forceinline__ int cell_coord(const Grid &g, float v, int a) {
+    int c = (int)floor(((double)v - (double)g.mn[a]) * g.inv_h);
+    c = c < 0 ? 0 : c;
+    return c >= g.dim[a] ? g.dim[a] - 1 : c;
+}
+
+__device__ __forceinline__ uint32_t cell_of(const Grid &g, float x, float y, float z) {
+    return (uint32_t)cell_coord(g, x, 0) + (uint32_t)g.dim[0] * ((uint32_t)cell_coord(g, y, 1) + (uint32_t)g.dim[1] * (uint32_t)cell_coord(g, z, 2));
+}
+
+// ---- bounding box ----
+__global__ void __launch_bounds__(BLK) bbox_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
+                                                  float *__restrict__ partial /* [gridDim.x][6] */) {
+    __shared__ float red[6][BLK / 64];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        float v[3] = {x[i], y[i], z[i]};
+        if (!(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]))) continue;
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], v[a]); hi[a] = fmaxf(hi[a], v[a]); }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[threadIdx.x][0];
+        for (int w = 1; w < BLK / 64; w++) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+        partial[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// ---- occupancy probe / counting sort ----
+__global__ void __launch_bounds__(BLK) cell_count_kernel(Grid g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                        size_t n, uint32_t *__restrict__ counts, uint32_t *__restrict__ cell_id) {
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        uint32_t c = cell_of(g, x[i], y[i], z[i]);
+        if (cell_id) cell_id[i] = c;
+        atomicAdd(&counts[c], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(BLK) count_nonzero_kernel(const uint32_t *__restrict__ counts, size_t ncells, uint32_t *__restrict__ out) {
+    uint32_t c = 0;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < ncells; i += (size_t)gridDim.x * BLK) c += counts[i] != 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// sorted[pos] = (x, y, z, original index)
+__global__ void __launch_bounds__(BLK) cell_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
+                                                          const uint32_t *__restrict__ cell_id, const uint32_t *__restrict__ cell_start,
+                                                          uint32_t *__restrict__ cell_fill, float4 *__restrict__ sorted) {
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        uint32_t c = cell_id[i];
+        uint32_t pos = cell_start[c] + atomicAdd(&cell_fill[c], 1u);
+        sorted[pos] = make_float4(x[i], y[i], z[i], __uint_as_float((uint32_t)i));
+    }
+}
+
+// ---- exact k-NN mean distance ----
+// One lane per point (in cell order, so a wave's lanes search the same shells).
+// best[] lives in LDS, one column per lane: best[j * QB + lane].
+constexpr int QB = 128;
+
+__global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid g, const float4 *__restrict__ sorted, size_t n, const uint32_t *__restrict__ cell_start,
+                                                          const uint32_t *__restrict__ cell_count, int k, float *__restrict__ dist_out) {
+    extern __shared__ float best_all[];
+    float *best = best_all + threadIdx.x;
+    const int want = k + 1;
+    size_t qi = (size_t)blockIdx.x * QB + threadIdx.x;
+    if (qi >= n) return;
+    const float4 q = sorted[qi];
+    const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+    int have = 0;
+    float worst = -1.0f;   // largest of the kept distances
+    int worst_at = 0;
+    const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int ring = 0; ring <= maxring; ring++) {
+        for (int dz = -ring; dz <= ring; dz++) {
+            const int z = cz + dz;
+            if (z < 0 || z >= g.dim[2]) continue;
+            for (int dy = -ring; dy <= ring; dy++) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.dim[1]) continue;
+                const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
+                const int step = face ? 1 : (ring > 0 ? 2 * ring : 1);
+                for (int dx = -ring; dx <= ring; dx += step) {
+                    const int x = cx + dx;
+                    if (x < 0 || x >= g.dim[0]) continue;
+                    const uint32_t c = (uint32_t)x + (uint32_t)g.dim[0] * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
+                    const uint32_t first = cell_start[c], cnt = cell_count[c];
+                    for (uint32_t e = first; e < first + cnt; e++) {
+                        const float4 p = sorted[e];
+                        // FLANN L2_Simple<float>: separately rounded fp32 operations, x,y,z order
+                        float d = __fsub_rn(q.x, p.x);
+                        float d2 = __fmul_rn(d, d);
+                        d = __fsub_rn(q.y, p.y);
+                        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+                        d = __fsub_rn(q.z, p.z);
+                        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+                        if (have < want) {
+                            best[have * QB] = d2;
+                            if (d2 > worst) { worst = d2; worst_at = have; }
+                            have++;
+                        } else if (d2 < worst) {
+                            best[worst_at * QB] = d2;
+                            worst = -1.0f;
+                            for (int j = 0; j < want; j++) {
+                                float v = best[j * QB];
+                                if (v > worst) { worst = v; worst_at = j; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (have == want) {
+            const double reach = (double)ring * g.h;
+            if ((double)worst < reach * reach * (1.0 - 1e-6)) break;
+        }
+    }
+    // ascending order, then the f64 sum of fp32 square roots, skipping the query itself
+    for (int a = 1; a < have; a++) {
+        float v = best[a * QB];
+        int b = a;
+        while (b > 0 && best[(b - 1) * QB] > v) { best[b * QB] = best[(b - 1) * QB]; b--; }
+        best[b * QB] = v;
+    }
+    double sum = 0.0;
+    for (int j = 1; j < have; j++) sum += (double)sqrtf(best[j * QB]);
+    dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
+}
+
+// ---- mean / variance, deterministic two-level sum ----
+__global__ void __launch_bounds__(BLK) stats_partial_kernel(const float *__restrict__ d, size_t n, double *__restrict__ partial) {
+    __shared__ double red[2][BLK / 64];
+    double s = 0, q = 0;
+    // contiguous slice per workgroup, strided by lane inside it: fixed order for a fixed launch shape
+    size_t per = (n + gridDim.x - 1) / gridDim.x;
+    size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += BLK) {
+        float v = d[i];
+        s += (double)v;
+        q += (double)__fmul_rn(v, v);   // "distance * distance" is an fp32 product upstream
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        q += __shfl_down(q, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0, tq = 0;
+        for (int w = 0; w < BLK / 64; w++) { ts += red[0][w]; tq += red[1][w]; }
+        partial[2 * blockIdx.x] = ts;
+        partial[2 * blockIdx.x + 1] = tq;
+    }
+}
+
+static inline unsigned grid_for(size_t n) {
+    size_t g = (n + BLK - 1) / BLK;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return false;
+    const size_t n = src.npoints;
+    if (n == 0) return true;
+    if (k < 1) {
+        CW_HIP_TRY(hipMemsetAsync(dev_dist, 0, n * sizeof(float), c.stream));
+        return c.sync();
+    }
+    if (k > 120) {   // (k+1) * 128 lanes * 4 B of LDS per workgroup must stay below 64 KiB
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_remove_outliers", "kNeighbors > 120 is not supported by the HIP path");
+        return false;
+    }
+
+    // 1. bounding box
+    const unsigned nb = grid_for(n);
+    float *partial = (float *)pool_alloc((size_t)nb * 6 * sizeof(float));
+    if (!partial) return false;
+    CW_LAUNCH("sor_bbox", bbox_kernel, dim3(nb), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, partial);
+    float *hpart = (float *)c.staging((size_t)nb * 6 * sizeof(float));
+    bool ok = hpart && hipMemcpyAsync(hpart, partial, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    ok = c.sync() && ok;
+    pool_free(partial);
+    if (!ok) return false;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (unsigned b = 0; b < nb; b++)
+        for (int a = 0; a < 3; a++) {
+            mn[a] = fminf(mn[a], hpart[b * 6 + a]);
+            mx[a] = fmaxf(mx[a], hpart[b * 6 + 3 + a]);
+        }
+    double ext[3], maxext = 0;
+    for (int a = 0; a < 3; a++) {
+        ext[a] = (double)mx[a] - (double)mn[a];
+        if (!(ext[a] >= 0)) ext[a] = 0;   // no finite point
+        if (ext[a] > maxext) maxext = ext[a];
+    }
+    if (!(maxext > 0)) maxext = 1.0;
+
+    auto make_grid = [&](double h) {
+        Grid g;
+        for (int a = 0; a < 3; a++) {
+            g.mn[a] = mn[a] == FLT_MAX ? 0.f : mn[a];
+            g.dim[a] = (int)floor(ext[a] / h) + 1;
+        }
+        g.h = h;
+        g.inv_h = 1.0 / h;
+        return g;
+    };
+    auto cells_of = [](const Grid &g) { return (size_t)g.dim[0] * (size_t)g.dim[1] * (size_t)g.dim[2]; };
+    // finest cell size whose dense grid stays within MAX_CELLS
+    double h_min = maxext / 1024.0;
+    while (cells_of(make_grid(h_min)) > MAX_CELLS) h_min *= 1.25;
+
+    uint32_t *counts = (uint32_t *)pool_alloc(MAX_CELLS * sizeof(uint32_t) + 256);
+    uint32_t *fill = (uint32_t *)pool_alloc(MAX_CELLS * sizeof(uint32_t));
+    uint32_t *cell_id = (uint32_t *)pool_alloc(n * sizeof(uint32_t));
+    float4 *sorted = (float4 *)pool_alloc(n * sizeof(float4));
+    void *scan_tmp = nullptr;
+    auto cleanup = [&]() { pool_free(counts); pool_free(fill); pool_free(cell_id); pool_free(sorted); pool_free(scan_tmp); };
+    if (!counts || !fill || !cell_id || !sorted) { cleanup(); return false; }
+
+    // 2. occupancy probe at h_min, then coarsen so that an occupied cell holds about (k+1)/3 points
+    //    (surface-like data: points per cell grow with h^2)
+    Grid g = make_grid(h_min);
+    size_t ncells = cells_of(g);
+    uint32_t *occ_dev = counts + MAX_CELLS;
+    ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess &&
+         hipMemsetAsync(occ_dev, 0, sizeof(uint32_t), c.stream) == hipSuccess;
+    if (ok) {
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, src.x(), src.y(), src.z(), n, counts, cell_id);
+        CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(grid_for(ncells)), dim3(BLK), 0, c.stream, counts, ncells, occ_dev);
+        ok = hipMemcpyAsync(c.host_words, occ_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    }
+    ok = c.sync() && ok;
+    if (!ok) { cleanup(); return false; }
+    double ppc = (double)n / (double)(c.host_words[0] ? c.host_words[0] : 1);
+    double target = (double)(k + 1) / 3.0;
+    if (ppc < target) {
+        double h = h_min * sqrt(target / ppc);
+        if (h > maxext) h = maxext;
+        g = make_grid(h);
+        ncells = cells_of(g);
+        ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess;
+        if (ok) CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, src.x(), src.y(), src.z(), n, counts, cell_id);
+    }
+
+    // 3. counting sort: exclusive scan of the counts, scatter
+    size_t tmp_bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, counts, fill, 0u, ncells, rocprim::plus<uint32_t>(), c.stream);
+    if (e == hipSuccess) {
+        scan_tmp = pool_alloc(tmp_bytes ? tmp_bytes : 256);
+        if (!scan_tmp) e = hipErrorOutOfMemory;
+    }
+    if (e == hipSuccess) {
+        if (profiling_enabled()) profile_begin("sor_exclusive_scan", c.stream);
+        // fill <- starts ; counts stays ; a second buffer then serves as the fill cursor
+        e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, counts, fill, 0u, ncells, rocprim::plus<uint32_t>(), c.stream);
+        if (profiling_enabled()) profile_end(c.stream);
+    }
+    if (e != hipSuccess || !ok) {
+        hip_failed(e, "rocprim::exclusive_scan", __FILE__, __LINE__);
+        cleanup();
+        return false;
+    }
+    uint32_t *starts = fill;
+    uint32_t *cursor = (uint32_t *)pool_alloc(ncells * sizeof(uint32_t));
+    if (!cursor) { cleanup(); return false; }
+    ok = hipMemsetAsync(cursor, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess;
+    if (ok) {
+        CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts,
+                  cursor, sorted);
+        // 4. the k-NN pass
+        const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
+        const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
+        CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+    }
+    ok = c.sync() && ok;
+    pool_free(cursor);
+    cleanup();
+    if (!ok) hip_failed(hipGetLastError(), "sor k-NN", __FILE__, __LINE__);
+    return ok;
+}
+
+bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *thr) {
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return false;
+    const unsigned nb = 1024;
+    double *partial = (double *)pool_alloc(nb * 2 * sizeof(double));
+    if (!partial) return false;
+    CW_LAUNCH("sor_stats", stats_partial_kernel, dim3(nb), dim3(BLK), 0, c.stream, dev_dist, n, partial);
+    double *h = (double *)c.staging(nb * 2 * sizeof(double));
+    bool ok = h && hipMemcpyAsync(h, partial, nb * 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    ok = c.sync() && ok;
+    pool_free(partial);
+    if (!ok) return false;
+    double sum = 0, sq_sum = 0;
+    for (unsigned b = 0; b < nb; b++) { sum += h[2 * b]; sq_sum += h[2 * b + 1]; }
+    // pcl::StatisticalOutlierRemoval: every point is "valid" here (finite input)
+    double valid = (double)n;
+    double mean = sum / valid;
+    double variance = (sq_sum - sum * sum / valid) / (valid - 1);
+    double stddev = sqrt(variance);
+    *thr = mean + (double)stddev_mul * stddev;
+    return true;
+}
+
+std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr) {
+    k::Predicate p{};
+    p.mode = 3;
+    p.dist = dev_dist;
+    p.thr = thr;
+    return compact(src, p);
+}
+
+}  // namespace cwipc_amd

@@ -1,0 +1,65 @@
+/*
+ * cwipc_util_amd/hip_ext.h -- device-side extensions of the MI355X libcwipc_util.
+ *
+ * None of these symbols exist in the reference; they expose what a GPU-resident
+ * pipeline needs on top of the drop-in C-ABI of cwipc_util/api.h: device
+ * selection, explicit residency control, zero-copy access to the SoA planes
+ * (so torch.distributed / RCCL can move them), two filters whose reference
+ * implementation is Python-side, and per-kernel timing for bench.py.
+ * Plain C: pointers and sizes only, no torch types.
+ */
+#ifndef CWIPC_UTIL_AMD_HIP_EXT_H
+#define CWIPC_UTIL_AMD_HIP_EXT_H
+
+#include "cwipc_util/api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device management ---- */
+_CWIPC_UTIL_EXPORT int cwipc_hip_device_count(void);          /* 0 when no GPU is visible */
+_CWIPC_UTIL_EXPORT int cwipc_hip_set_device(int device);      /* process-wide device for all later calls; 0 ok, -1 error */
+_CWIPC_UTIL_EXPORT int cwipc_hip_get_device(void);
+_CWIPC_UTIL_EXPORT const char *cwipc_hip_last_error(void);    /* thread-local text of the last HIP failure ("" if none) */
+_CWIPC_UTIL_EXPORT void cwipc_hip_synchronize(void);          /* wait for the calling thread's stream */
+_CWIPC_UTIL_EXPORT size_t cwipc_hip_pool_bytes(void);         /* bytes currently held by the device memory pool */
+_CWIPC_UTIL_EXPORT void cwipc_hip_pool_trim(void);            /* return cached device memory to the driver */
+
+/* ---- residency ----
+ * A cloud made by cwipc_from_points lives in host memory until a filter needs
+ * it; filter results live in HBM (SoA planes x,y,z:f32[n], rgbt:u32[n] with
+ * r | g<<8 | b<<16 | tile<<24) until a host accessor needs them. */
+_CWIPC_UTIL_EXPORT int cwipc_hip_upload(cwipc_pointcloud *pc);            /* make the SoA copy now; 0 ok */
+_CWIPC_UTIL_EXPORT int cwipc_hip_drop_host_copy(cwipc_pointcloud *pc);    /* free the host AoS copy (device copy must exist) */
+_CWIPC_UTIL_EXPORT int cwipc_hip_is_device_resident(cwipc_pointcloud *pc);
+_CWIPC_UTIL_EXPORT int cwipc_hip_device_planes(cwipc_pointcloud *pc, const float **x, const float **y, const float **z,
+                                               const uint32_t **rgbt, size_t *npoint);
+/* Interleave the planes into a DEVICE buffer of npoint*16 bytes (cwipc_point records). Returns npoint or -1. */
+_CWIPC_UTIL_EXPORT long cwipc_hip_copy_device_aos(cwipc_pointcloud *pc, void *dev_points, size_t size);
+/* New cloud from cwipc_point records that already are in device memory. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_aos(const void *dev_points, size_t npoint, uint64_t timestamp, float cellsize);
+
+/* ---- filters whose reference implementation is Python-side ---- */
+/* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid);
+/* cwipc_join_multi (reference python/cwipc/util.py:1330-1332): same result as the left fold of cwipc_join, one pass. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int npc);
+/* cwipc_tilefilter_masked (reference python/cwipc/registration/util.py:98-112): keep points with (tile & mask) != 0. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_tilefilter_masked(cwipc_pointcloud *pc, int mask);
+
+/* ---- intermediate results for parity tests ---- */
+/* Mean k-NN distance d_i of every point (the quantity pcl::StatisticalOutlierRemoval thresholds) into host memory; 0 ok. */
+_CWIPC_UTIL_EXPORT int cwipc_hip_knn_mean_dist(cwipc_pointcloud *pc, int kNeighbors, float *mean_dist, size_t cap, double *threshold, float stddevMulThresh);
+
+/* ---- per-kernel device timing (hipEvents on the calling thread's stream) ---- */
+_CWIPC_UTIL_EXPORT void cwipc_hip_profile_enable(int on);
+_CWIPC_UTIL_EXPORT void cwipc_hip_profile_reset(void);
+/* Number of distinct kernels seen; name/total milliseconds/launch count of entry i. */
+_CWIPC_UTIL_EXPORT int cwipc_hip_profile_count(void);
+_CWIPC_UTIL_EXPORT int cwipc_hip_profile_get(int i, const char **name, double *total_ms, long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
