@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: voxel downsample of a 10 M-point synthetic cloud.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): cwipc_synthetic(npoints=10 000 000) -> N = 9 998 244 points
+(159 971 904 B), device-resident; one step = one cwipc_downsample(pc, +0.01) through the C-ABI
+(octree-split path, the reference's default).  Steps rotate over 4 distinct device copies
+(640 MB > the 256 MB Infinity Cache) so every step reads cold HBM.
+
+N > 1 (weak scaling): every rank holds one camera tile of the same size (tile mask 1 << rank),
+runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join
+(cwipc_util_amd.multigpu) -- the path's one exchange step.
+
+One JSON line on rank 0.  `value` = points filtered by all ranks / wall time of the K timed steps
+(max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel
+(16 B per input point + 16 B per output point) / its mean launch duration, measured with hipEvents
+on the library's stream during a second pass over the same steps.  `cpu_baseline` = the CPU oracle
+(a single-threaded C restatement of the PCL algorithm, NOT PCL) on the same cloud, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+NPOINTS_ARG = 10_000_000
+CELLSIZE = 0.01
+NCOPIES = 4
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_input(cwipc, npoints_arg: int, angle: float):
+    """The synthetic cloud through the product's own source (amd-fixangle pins the colours)."""
+    import struct
+    src = cwipc.cwipc_synthetic(0, npoints_arg)
+    src.start()
+    out = bytearray(4)
+    assert src.auxiliary_operation("amd-fixangle", struct.pack("f", angle), out)
+    pc = src.get()
+    src.stop()
+    return pc
+
+
+def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 12.0):
+    """Time the oracle's downsample on the host (1 thread).  Test infrastructure used as the CPU baseline."""
+    from oracle import oracle
+    try:
+        lib = oracle.load(native=True)   # -march=native copy built on this host
+        kind_note = "gcc -O3 -march=native"
+    except Exception:
+        lib = oracle.load()
+        kind_note = "gcc -O3"
+    import ctypes
+    out = np.zeros(len(points), dtype=oracle.POINT_DTYPE)
+    ocs = ctypes.c_float(0)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
+        t0 = time.perf_counter()
+        m = lib.oracle_downsample(points.ctypes.data, len(points), pc_cellsize, CELLSIZE, out.ctypes.data, len(out),
+                                  ctypes.addressof(ocs), None, None)
+        times.append(time.perf_counter() - t0)
+        assert m > 0
+    best = float(np.median(times))
+    return {
+        "value": len(points) / best / 1e6,
+        "unit": "Mpoints/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"full workload ({len(points)} points), median of {len(times)} runs, {kind_note}; "
+                  "C restatement of pcl::VoxelGrid + octree split, not PCL",
+        "outputs": int(m),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--npoints", type=int, default=NPOINTS_ARG)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import cwipc_util_amd as cwipc
+
+    if cwipc.cwipc_hip_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the filter path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    cwipc.cwipc_hip_set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- input: 4 device-resident copies of this rank's tile ----
+    base = make_input(cwipc, args.npoints, angle=0.25 * rank)
+    pts = base.get_numpy_array().copy()
+    if world > 1:
+        pts['tile'] = 1 << (rank % 8)     # camera mask of this rank's tile
+    pc_cellsize = base.cellsize()
+    n = len(pts)
+    clouds = []
+    for _ in range(NCOPIES):
+        pc = cwipc.cwipc_from_numpy_array(pts, 1000 + rank)
+        pc._set_cellsize(pc_cellsize)
+        cwipc.cwipc_hip_upload(pc, drop_host_copy=True)
+        clouds.append(pc)
+    del base
+
+    def step(i: int):
+        out = cwipc.cwipc_downsample(clouds[i % NCOPIES], CELLSIZE)
+        if world > 1:
+            from cwipc_util_amd.multigpu import join_across_ranks
+            out = join_across_ranks(out)
+        return out
+
+    def fence():
+        cwipc.util.cwipc_util_dll_load().cwipc_hip_synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    n_out = 0
+    for i in range(args.warmup):
+        n_out = step(i).count()
+
+    # ---- timed region ----
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fused_points = out.count()
+
+    # ---- second pass over the same steps with per-kernel hipEvent timing ----
+    with cwipc.cwipc_hip_profile() as prof:
+        for i in range(args.steps):
+            cwipc.cwipc_downsample(clouds[i % NCOPIES], CELLSIZE)
+    kernels = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": v[0] / max(v[1], 1)} for k, v in prof.kernels.items()}
+    dominant = max(kernels, key=lambda k: kernels[k]["ms_total"])
+    dom_ms = kernels[dominant]["ms_avg"]
+    all_ms = sum(v["ms_total"] for v in kernels.values()) / args.steps
+    algorithmic_bytes = 16 * n + 16 * n_out
+    achieved = algorithmic_bytes / (dom_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        result = {
+            "metric": "Mpoints/s filtered (voxel downsample, 10M-pt synthetic) + achieved HBM GB/s",
+            "value": world * n * args.steps / elapsed / 1e6,
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 coordinates in, i64 fixed-point sums, u8 colours",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cwipc_synthetic({args.npoints}) -> cwipc_downsample(+{CELLSIZE}) [BASELINE configs[1]]"
+                            + (f" per rank, tile masks 1<<rank, + all-gatherv join over {world} ranks" if world > 1 else ""),
+                "points_per_gpu": n,
+                "bytes_per_gpu": 16 * n,
+                "outputs_per_gpu": n_out,
+                "fused_points": fused_points,
+                "input_copies_rotated": NCOPIES,
+                "inputs_resident_in_hbm": True,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dominant,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algorithmic_bytes,
+                "kernel_ms_avg": dom_ms,
+                "all_kernels_ms_per_step": all_ms,
+                "achieved_all_kernels": algorithmic_bytes / (all_ms * 1e-3) / 1e9,
+                "frac_all_kernels": algorithmic_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            },
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(pts, pc_cellsize)
+        print(json.dumps(result))
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,266 @@
+"""The drop-in boundary without a GPU: the library loads, exports every symbol the
+headers declare, and the container / source / logging behaviour matches what the
+reference's tests pin (reference python/test_cwipc_util.py).  No filter is run here."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_cloud
+
+
+def _declared_symbols():
+    names = []
+    for rel in ("include/cwipc_util/api.h", "include/cwipc_util_amd/hip_ext.h"):
+        text = open(os.path.join(ROOT, rel)).read()
+        names += [n for n in re.findall(r"^\s*_CWIPC_UTIL_EXPORT[^;(]*?\b(\w+)\s*\(", text, flags=re.M) if n != "__attribute__"]
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(cwipc):
+    dll = cwipc.cwipc_util_dll_load()
+    declared = _declared_symbols()
+    assert len(declared) > 70
+    missing = [n for n in declared if not hasattr(dll, n)]
+    assert not missing, missing
+    # the symbols the reference wrapper binds eagerly (reference python/cwipc/util.py:387-550)
+    for n in ("cwipc_downsample", "cwipc_remove_outliers", "cwipc_tilefilter", "cwipc_tilemap", "cwipc_colormap",
+              "cwipc_crop", "cwipc_join", "cwipc_from_points", "cwipc_from_packet", "cwipc_pointcloud_copy_uncompressed",
+              "cwipc_pointcloud_copy_packet", "cwipc_synthetic", "cwipc_capturer", "cwipc_window", "cwipc_proxy",
+              "cwipc_read", "cwipc_write_ext", "cwipc_read_debugdump", "cwipc_write_debugdump"):
+        assert n in declared
+
+
+def test_point(cwipc):
+    p = cwipc.cwipc_point(1, 2, 3, 0x10, 0x20, 0x30, 0)
+    assert (p.x, p.y, p.z, p.r, p.g, p.b) == (1, 2, 3, 0x10, 0x20, 0x30)
+    assert ctypes.sizeof(cwipc.cwipc_point) == 16
+
+
+def test_pointarray(cwipc):
+    p = cwipc.cwipc_point_array(count=10)
+    assert p[0].x == 0 and p[9].b == 0
+    with pytest.raises(IndexError):
+        p[10].x
+    p = cwipc.cwipc_point_array(values=[(1, 2, 3, 0x10, 0x20, 0x30, 0), (4, 5, 6, 0x40, 0x50, 0x60, 0)])
+    assert len(p) == 2 and p[1].x == 4 and p[1].b == 0x60
+
+
+def test_empty_wrappers(cwipc):
+    pc = cwipc.cwipc_pointcloud_wrapper()
+    del pc
+    pcs = cwipc.cwipc_source_wrapper()
+    del pcs
+
+
+def _build_pointcloud(cwipc):
+    points = cwipc.cwipc_point_array(values=[(1, 2, 3, 0x10, 0x20, 0x30, 1), (4, 5, 6, 0x40, 0x50, 0x60, 2)])
+    return cwipc.cwipc_from_points(points, 0), points
+
+
+def test_from_points(cwipc):
+    assert len(cwipc.cwipc_from_points(cwipc.cwipc_point_array(values=[]), 0).get_points()) == 0
+    pc, points = _build_pointcloud(cwipc)
+    assert pc.count() == 2
+    assert list(pc.get_points()) == list(points)
+
+
+def test_numpy_roundtrips(cwipc):
+    pc, points = _build_pointcloud(cwipc)
+    arr = pc.get_numpy_array()
+    assert arr.shape[0] == 2
+    assert list(cwipc.cwipc_from_numpy_array(arr, 0).get_points()) == list(points)
+    m = pc.get_numpy_matrix()
+    assert m.shape == (2, 7)
+    assert list(cwipc.cwipc_from_numpy_matrix(m, 0).get_points()) == list(points)
+
+
+def test_timestamp_cellsize(cwipc):
+    timestamp = 0x11223344556677
+    pc = cwipc.cwipc_from_points([(0, 0, 0, 0, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1), (2, 0, 0, 0, 0, 0, 1), (3, 0, 0, 0, 0, 0, 1)], timestamp)
+    assert pc.timestamp() == timestamp
+    pc._set_timestamp(timestamp + 1)
+    assert pc.timestamp() == timestamp + 1
+    assert pc.cellsize() == 0
+    pc._set_cellsize(0.1)
+    assert pc.cellsize() == pytest.approx(0.1)
+    pc._set_cellsize(-1)
+    assert pc.cellsize() == pytest.approx(1.0)
+
+
+def test_dangling_allocations_and_clone(cwipc):
+    import gc
+    gc.collect()
+    old = cwipc.cwipc_dangling_allocations(True)
+    pc, _ = _build_pointcloud(cwipc)
+    assert cwipc.cwipc_dangling_allocations(True) == old + 1
+    clone = pc.clone()
+    assert cwipc.cwipc_dangling_allocations(False) == old + 2
+    assert clone.count() == pc.count() and clone.timestamp() == pc.timestamp()
+    assert list(clone.get_points()) == list(pc.get_points())
+    pc = None
+    clone = None
+    gc.collect()
+    assert cwipc.cwipc_dangling_allocations(False) == old
+
+
+def test_free_is_idempotent(cwipc):
+    pc, _ = _build_pointcloud(cwipc)
+    dll = cwipc.cwipc_util_dll_load()
+    p = pc.detach()
+    dll.cwipc_pointcloud_free(p.as_cwipc_p())
+    dll.cwipc_pointcloud_free(p.as_cwipc_p())
+    assert dll.cwipc_pointcloud_count(p.as_cwipc_p()) == 0
+
+
+def test_read_write_ply_fail_loudly(cwipc, tmp_path):
+    pc, _ = _build_pointcloud(cwipc)
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_read(str(tmp_path / "nonexistent.ply"), 1234)
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_write(str(tmp_path / "out.ply"), pc)
+
+
+def test_debugdump(cwipc, tmp_path):
+    pc, _ = _build_pointcloud(cwipc)
+    pc._set_cellsize(0.25)
+    fn = str(tmp_path / "x.cwipcdump")
+    cwipc.cwipc_write_debugdump(fn, pc)
+    raw = open(fn, "rb").read()
+    assert raw[:4] == b"cpcd" and struct.unpack("<I", raw[4:8])[0] == 0x20210208 and len(raw) == 32 + 2 * 16
+    pc2 = cwipc.cwipc_read_debugdump(fn)
+    assert list(pc.get_points()) == list(pc2.get_points())
+    assert pc2.cellsize() == 0.25
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_write_debugdump(str(tmp_path / "non" / "existent"), pc)
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_read_debugdump(str(tmp_path / "missing.cwipcdump"))
+
+
+def test_packet(cwipc):
+    pc, _ = _build_pointcloud(cwipc)
+    pc._set_cellsize(0.5)
+    packet = pc.get_packet()
+    pc2 = cwipc.cwipc_from_packet(packet)
+    assert pc.timestamp() == pc2.timestamp() and pc.cellsize() == pc2.cellsize()
+    assert list(pc.get_points()) == list(pc2.get_points())
+    assert pc2.get_packet() == packet
+    bad = bytearray(packet)
+    bad[0] = ord('x')
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_from_packet(bytes(bad))
+
+
+def test_api_version_is_checked(cwipc):
+    dll = cwipc.cwipc_util_dll_load()
+    err = ctypes.c_char_p()
+    rv = dll.cwipc_synthetic(0, 0, ctypes.byref(err), 0x20200101)
+    assert not rv and b"incorrect apiVersion" in err.value
+
+
+def test_logger(cwipc):
+    messages = []
+    cwipc.cwipc_log_configure(cwipc.CWIPC_LOG_LEVEL_DEBUG, lambda level, msg: messages.append((level, msg.decode('utf8'))))
+    cwipc._cwipc_log_emit(cwipc.CWIPC_LOG_LEVEL_DEBUG, "test_module", "This is a test log message")
+    assert any("This is a test log message" in m and lvl == cwipc.CWIPC_LOG_LEVEL_DEBUG for lvl, m in messages)
+    cwipc.cwipc_log_configure(cwipc.CWIPC_LOG_LEVEL_WARNING, None)
+
+
+def test_synthetic_source(cwipc, oracle):
+    pcs = cwipc.cwipc_synthetic()
+    assert pcs.start()
+    assert pcs.available(True) and not pcs.eof()
+    pc = pcs.get()
+    assert pc is not None and pc.count() == 160000
+    assert pc.cellsize() == pytest.approx(2.0 / 400)
+    # geometry and tiles do not depend on the angle: identical to the oracle's generator
+    exp, _ = oracle.synthetic(0, 0.0)
+    got = pc.get_numpy_array()
+    for f in ('x', 'y', 'z', 'tile'):
+        assert (got[f] == exp[f]).all()
+    pcs.stop()
+    # fps throttling (reference test_cwipc_synthetic_available_false)
+    pcs = cwipc.cwipc_synthetic(5)
+    assert pcs.start() and pcs.available(True)
+    pcs.get()
+    assert not pcs.available(False)
+    pcs.stop()
+    pcs = cwipc.cwipc_synthetic(10, 1000)
+    pcs.start()
+    assert pcs.get().count() == 31 * 31
+
+
+def test_synthetic_fixed_angle_matches_oracle(cwipc, oracle):
+    pcs = cwipc.cwipc_synthetic(0, 100000)
+    pcs.start()
+    out = bytearray(4)
+    assert pcs.auxiliary_operation("amd-fixangle", struct.pack("f", 0.75), out)
+    got = pcs.get().get_numpy_array()
+    exp, _ = oracle.synthetic(100000, 0.75)
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_synthetic_metadata_auxop_tiles_config(cwipc):
+    pcs = cwipc.cwipc_synthetic()
+    assert not pcs.is_metadata_requested("nonexistent-metadata")
+    pcs.request_metadata("test-angle")
+    assert pcs.is_metadata_requested("test-angle")
+    assert pcs.start()
+    pc = pcs.get()          # keep the cloud alive: the metadata belongs to it
+    ap = pc.access_metadata()
+    assert ap.count() == 1 and ap.name(0) == "test-angle" and ap.description(0) == "" and ap.size(0) == 4 and len(ap.data(0)) == 4
+    assert not pcs.auxiliary_operation("nonexistent-auxop", bytes(), bytearray(4))
+    outbuf = bytearray(struct.pack("f", 0))
+    assert pcs.auxiliary_operation("test-setangle", struct.pack("f", 42.0), outbuf)
+    assert struct.unpack("f", outbuf)[0] == 42.0
+    assert pcs.maxtile() == 3
+    assert pcs.get_tileinfo_dict(0) == {'normal': {'x': 0, 'y': 0, 'z': 0}, 'cameraName': b'synthetic', 'ncamera': 2, 'cameraMask': 0}
+    assert pcs.get_tileinfo_dict(1) == {'normal': {'x': 0, 'y': 0, 'z': 1}, 'cameraName': b'synthetic-right', 'ncamera': 1, 'cameraMask': 1}
+    assert pcs.get_tileinfo_dict(2) == {'normal': {'x': 0, 'y': 0, 'z': -1}, 'cameraName': b'synthetic-left', 'ncamera': 1, 'cameraMask': 2}
+    assert not pcs.reload_config("auto")
+    with pytest.raises(cwipc.CwipcError):
+        pcs.get_config()
+    pcs.stop()
+
+
+def test_out_of_scope_constructors_fail_loudly(cwipc):
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_capturer('{"type":"nonexistent"}')
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_window("x")
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_proxy("", 8887)
+
+
+def test_metadata_empty(cwipc):
+    pc, _ = _build_pointcloud(cwipc)
+    md = pc.access_metadata()
+    assert md is not None and md.count() == 0
+
+
+def test_filters_fail_loudly_without_gpu(cwipc):
+    """The product has no CPU fallback: without a device every filter reports an error."""
+    if cwipc.cwipc_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    pc, _ = _build_pointcloud(cwipc)
+    for call in (lambda: cwipc.cwipc_tilefilter(pc, 1), lambda: cwipc.cwipc_downsample(pc, 0.1),
+                 lambda: cwipc.cwipc_remove_outliers(pc, 4, 1.0, False), lambda: cwipc.cwipc_colormap(pc, 0, 0),
+                 lambda: cwipc.cwipc_join(pc, pc), lambda: cwipc.cwipc_crop(pc, [0, 1, 0, 1, 0, 1]),
+                 lambda: cwipc.cwipc_tilemap(pc, {1: 2})):
+        with pytest.raises(cwipc.CwipcError, match="no usable HIP device"):
+            call()
+
+
+def test_product_does_not_import_the_oracle():
+    """Nothing under cwipc_util_amd/ may reference oracle/."""
+    pkg = os.path.join(ROOT, "cwipc_util_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        if os.path.basename(dirpath) in ("build", "lib", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
