@@ -191,9 +191,17 @@ def check_downsample(gpu, oracle, pts, pc_cellsize, cellsize, ordered=True):
     if not ordered:
         got = np.sort(got, order=['z', 'y', 'x'])
         exp = np.sort(exp, order=['z', 'y', 'x'])
+    # The bar is 1e-5 wherever a voxel holds at most a few hundred points (every BASELINE
+    # configuration: <= 254 points per voxel).  The reference algorithm keeps an fp32 running
+    # sum per voxel (pcl AccumulatorXYZ), whose own rounding error grows with the number of
+    # points in the voxel; the HIP path sums exact integers and rounds once.  For coarse
+    # cells (thousands of points per voxel) the bound therefore widens with that error model.
+    avg = len(pts) / max(len(exp), 1)
+    maxabs = max(float(np.abs(pts[f]).max()) for f in ('x', 'y', 'z')) if len(pts) else 0.0
+    tol = XYZ_TOL if avg <= 300 else max(XYZ_TOL, 8.0 * np.sqrt(avg) * 2.0 ** -24 * maxabs)
     for f in ('x', 'y', 'z'):
         err = np.abs(got[f].astype(np.float64) - exp[f].astype(np.float64)).max() if len(got) else 0.0
-        assert err <= XYZ_TOL, (f, err)
+        assert err <= tol, (f, err, tol)
     for f in ('r', 'g', 'b', 'tile'):
         assert (got[f] == exp[f]).all(), f
     return got, exp
@@ -229,6 +237,27 @@ def test_downsample_reference_loop(gpu, synth):
                 break
             cellsize *= 2
         assert count <= 8
+
+
+def test_downsample_means_are_correctly_rounded(gpu, oracle, synth):
+    """Independent of the oracle: voxel means against numpy float64 (plain grid, where grouping is a lexsort)."""
+    for cell, npoints in ((0.01, 300000), (0.3, 100000), (2.0, 100000)):
+        pts, cs = synth(npoints, 0.4)
+        got = gpu.cwipc_downsample(make_cloud(gpu, pts, cs), -cell).get_numpy_array()
+        leaf = np.float32(max(cell, cs))
+        inv = np.float32(1.0) / leaf
+        ijk = np.stack([np.floor(pts[f] * inv).astype(np.int64) for f in ('x', 'y', 'z')], axis=1)
+        order = np.lexsort((ijk[:, 0], ijk[:, 1], ijk[:, 2]))
+        sk = ijk[order]
+        start = np.flatnonzero(np.r_[True, (sk[1:] != sk[:-1]).any(axis=1)])
+        cnt = np.diff(np.r_[start, len(pts)])
+        assert len(got) == len(start)
+        for f in ('x', 'y', 'z'):
+            mean = np.add.reduceat(pts[f][order].astype(np.float64), start) / cnt
+            err = np.abs(got[f].astype(np.float64) - mean)
+            # fixed-point resolution is leaf * 2^-23; final rounding to fp32 adds half an ulp
+            assert err.max() <= float(leaf) * 2.0 ** -22 + np.spacing(np.float32(np.abs(mean).max())), (cell, f, err.max())
+        assert (got['tile'] == np.bitwise_or.reduceat(pts['tile'][order], start)).all()
 
 
 def test_downsample_permuted_input(gpu, oracle, synth):
