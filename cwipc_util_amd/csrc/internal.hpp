@@ -102,14 +102,18 @@ bool profiling_enabled();
 // ---------------------------------------------------------------------------
 
 // Device representation: four planes in one pool block, each plane `stride`
-// elements long (stride = npoints rounded up to 64 so every plane starts on a
-// 256-byte boundary).  rgbt = r | g<<8 | b<<16 | tile<<24, i.e. the last four
+// elements long (stride = npoints rounded up to 256, so every plane starts on a
+// 1 KiB boundary and a full wave step of 256 points can always be loaded).  rgbt = r | g<<8 | b<<16 | tile<<24, i.e. the last four
 // bytes of a cwipc_point read as one little-endian word.
 struct DeviceSoA {
     void *base = nullptr;
     size_t npoints = 0;
     size_t stride = 0;
     int device = 0;
+    // The cloud's first point, when the host knows it (the octree lattice of cwipc_downsample is
+    // anchored there); fetched from the device on demand otherwise.
+    mutable bool has_first = false;
+    mutable float first[3] = {0, 0, 0};
     float *x() const { return (float *)base; }
     float *y() const { return (float *)base + stride; }
     float *z() const { return (float *)base + 2 * stride; }

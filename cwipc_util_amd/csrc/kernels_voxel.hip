@@ -20,19 +20,28 @@
 // constraints that shaped the kernel (scratch/ubench*.hip):
 //   * scattered global integer atomics retire at ~23 G requests/s chip-wide whatever their
 //     scope, but 8 lanes updating one 64-byte record cost ~1.3 requests (17 G records/s);
+//   * many lanes bumping ONE counter serialise at the memory side (40 k of them: ~250 us);
 //   * an LDS atomic costs 13-20 cycles per WAVE INSTRUCTION almost independent of the
-//     number of active lanes, so instructions have to be saved, not lanes.
+//     number of active lanes, so instructions have to be saved, not lanes;
+//   * f64 and out-of-line calls in the streaming loop cost more than the stream itself.
 // Hence:
+//   host                  the octree lattice is anchored at the cloud's first point, which the
+//                         host knows (or fetches once): it computes the anchor and, per axis, a
+//                         table of leaf-face thresholds with the octree's own f64 arithmetic
+//                         (the octree key floor((p - min)/res) is monotone in p, so "key >= m"
+//                         is exactly "p >= T(m)" for one float T(m)).
 //   K1 voxel_accumulate   persistent: one 1024-lane workgroup per CU, every wave streams a
-//                         contiguous range of the planes (dwordx4 per plane per lane).  Lanes
-//                         merge their own 4 points, DPP row-shifts merge runs across lanes,
-//                         and only run ends touch the workgroup's LDS hash table (64-bit
-//                         integer LDS atomics).  The table is flushed ONCE per workgroup into
-//                         dense per-leaf grids of 64-byte records, 8 lanes per record, with
-//                         returning 64-bit adds (the returned count tells the first toucher,
-//                         which appends the cell to the occupied list).  All sums are
-//                         fixed-point integers: results are bitwise reproducible.
-//                         Each wave also emits the bounding box of its range.
+//                         contiguous range of the planes (dwordx4 per plane per lane, next
+//                         step prefetched in registers).  fp32/integer only: voxel index,
+//                         leaf by threshold compare, fixed-point offset.  Lanes merge their own
+//                         4 points, DPP row shifts merge runs across lanes, and only run ends
+//                         touch the workgroup's LDS hash table (packed 64-bit LDS atomics).
+//                         The table is flushed ONCE per workgroup into dense per-leaf grids of
+//                         64-byte records, 8 lanes per record, with returning 64-bit adds (the
+//                         returned count tells the first toucher; first touches are listed per
+//                         workgroup and appended with one global atomic).  All sums are
+//                         integers: results are bitwise reproducible.  Each wave also emits the
+//                         bounding box of its range.
 //   K2 octree_replay      one workgroup replays the octree's bounding-box growth over the wave
 //                         boxes, re-reading only the ranges that trigger a growth step
 //                         (plain grid: reduces the boxes to the global one).
@@ -58,6 +67,7 @@ namespace {
 constexpr int K1_THREADS = 1024;
 constexpr int K1_WAVES = K1_THREADS / 64;
 constexpr int WAVE_STEP = 256;                 // points per wave per step (4 per lane)
+constexpr size_t MAX_POINTS_PER_WAVE = 3840;   // 15 steps; 16 waves -> at most 61440 points per workgroup
 constexpr int LTAB = 2048;                     // LDS table entries per workgroup
 constexpr int LTAB_PROBES = 32;
 constexpr int GRID_DIM = 68;                   // cells per axis of a leaf grid (64 + slack for fp rounding)
@@ -65,7 +75,10 @@ constexpr int CELLS = GRID_DIM * GRID_DIM * GRID_DIM;   // 314432 < 2^19
 constexpr int CELL_BITS = 19;
 constexpr uint32_t KEY_EMPTY = 0xffffffffu;
 constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
+constexpr int Q_BIAS = 64;                     // per-point bias of the packed offset sums (they never borrow)
 constexpr int RECORD_WORDS = 8;                // 64-byte records: sx sy sz cr gb tlo thi tor
+constexpr int FACES = 128;                     // leaf faces per axis with a precomputed threshold
+constexpr int FACE_BACK = 63;                  // the table starts 63 faces below the first point's leaf
 
 enum : uint32_t {
     ERR_RANGE = 1,           // voxel index outside +-2^26, or leaf index outside +-2^20
@@ -73,7 +86,7 @@ enum : uint32_t {
     ERR_DEPTH = 4,           // octree deeper than the sort key can express
     ERR_GRID_OVERFLOW = 8,   // pcl::VoxelGrid: "Leaf size is too small ... indices would overflow"
     ERR_LEAF_RANGE = 16,
-    ERR_FIRST_POINT = 32,    // the first point is not finite
+    ERR_FACE_TABLE = 32,     // a point lies beyond the threshold table (host reruns the exact variant)
     ERR_CELL_RANGE = 64,
     ERR_LIST_FULL = 128,
 };
@@ -90,9 +103,15 @@ struct VoxParams {
     float fix_scale;        // 2^22 / leaf (fp32)
     double leaf_d;
     double res;             // octree resolution (double)(float)(64 * leaf)
+    // anchor (host): first octree box and the voxel index of its lower corner
+    double mn0[3], mx0[3];
+    int depth0;
+    int ib[3];              // cell c of leaf l on axis a is voxel  c + ib[a] + 64*l - 2
+    int face_base[3];       // faces[a][i] is the threshold of face face_base[a] + i
     int leaf_split;
     uint32_t leaf_mask;     // leaf hash capacity - 1
     uint32_t list_cap;
+    uint32_t ablate;        // diagnostics only (CWIPC_VOXEL_ABLATE): skip parts of K1 to time the rest; results are wrong when non-zero
 };
 
 struct VoxWork {
@@ -101,18 +120,31 @@ struct VoxWork {
     uint32_t *occupied;              // list of (leaf id << 19 | cell) of touched records
     uint32_t *ctrl;
     float *bboxes;                   // [nranges][6]
+    const float *faces;              // [3][FACES] thresholds (positive cellsize only)
 };
 
-__device__ __forceinline__ uint64_t mix64(uint64_t k) {
+inline __host__ __device__ uint64_t mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
     k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
     k ^= k >> 33;
     return k;
 }
 
-// Octree box after the first point: adoptBoundingBoxToPoint's "octree is empty"
-// branch followed by getKeyBitSize() [PCL upstream octree_pointcloud.hpp].
-__device__ __forceinline__ void first_box(const double p[3], double res, double mn[3], double mx[3], int &depth) {
+__device__ __forceinline__ unsigned long long pack_leaf(int lx, int ly, int lz) {
+    return (1ull << 63) | ((unsigned long long)(uint32_t)(lx & 0x1fffff)) | ((unsigned long long)(uint32_t)(ly & 0x1fffff) << 21) |
+           ((unsigned long long)(uint32_t)(lz & 0x1fffff) << 42);
+}
+__device__ __forceinline__ int unpack_leaf(unsigned long long v, int axis) {
+    int t = (int)((v >> (21 * axis)) & 0x1fffff);
+    return (t << 11) >> 11;   // sign-extend 21 bits
+}
+
+// ---------------------------------------------------------------------------
+// host: anchor and face thresholds  [PCL upstream octree_pointcloud.hpp]
+// ---------------------------------------------------------------------------
+// Octree box after the first point: adoptBoundingBoxToPoint's "octree is empty" branch followed
+// by getKeyBitSize().
+void first_box(const double p[3], double res, double mn[3], double mx[3], int &depth) {
     const double eps = (double)FLT_EPSILON;
     unsigned max_key = 0;
     for (int a = 0; a < 3; a++) {
@@ -135,49 +167,26 @@ __device__ __forceinline__ void first_box(const double p[3], double res, double 
     }
 }
 
-// Leaf lattice anchor shared by K1, K3 and K4: mn0 = lower corner of the first octree box,
-// ib = floor(mn0 / leaf).  Cell c of leaf l on an axis is voxel  c + ib + 64*l - 2.
-struct Anchor {
-    double mn0[3];
-    int ib[3];
-};
-
-__device__ __forceinline__ Anchor make_anchor(const VoxParams &P, float p0x, float p0y, float p0z) {
-    Anchor A;
-    if (P.leaf_split) {
-        double pp[3] = {(double)p0x, (double)p0y, (double)p0z}, mx0[3];
-        int d0;
-        first_box(pp, P.res, A.mn0, mx0, d0);
-        for (int a = 0; a < 3; a++) A.ib[a] = (int)floor(A.mn0[a] / P.leaf_d);
-    } else {
-        // plain grid: "leaves" are bricks of 64^3 voxels aligned to the voxel lattice
-        for (int a = 0; a < 3; a++) { A.mn0[a] = 0; A.ib[a] = 2; }
+// The octree key of a coordinate, floor((p - min) / resolution) in double (genOctreeKeyforPoint),
+// is monotone in p: "key >= m" is a threshold test p >= T(m).  Smallest float that passes.
+float leaf_threshold(double mn0, double res, int m) {
+    const double md = (double)m;
+    float c = (float)(mn0 + md * res);
+    for (int i = 0; i < 8; i++) {
+        const float p = nextafterf(c, -INFINITY);
+        if (floor(((double)p - mn0) / res) >= md) c = p; else break;
     }
-    return A;
+    for (int i = 0; i < 8; i++) {
+        if (floor(((double)c - mn0) / res) >= md) break;
+        c = nextafterf(c, INFINITY);
+    }
+    return c;
 }
-
-__device__ __forceinline__ unsigned long long pack_leaf(int lx, int ly, int lz) {
-    return (1ull << 63) | ((unsigned long long)(uint32_t)(lx & 0x1fffff)) | ((unsigned long long)(uint32_t)(ly & 0x1fffff) << 21) |
-           ((unsigned long long)(uint32_t)(lz & 0x1fffff) << 42);
-}
-__device__ __forceinline__ int unpack_leaf(unsigned long long v, int axis) {
-    int t = (int)((v >> (21 * axis)) & 0x1fffff);
-    return (t << 11) >> 11;   // sign-extend 21 bits
-}
-
-// One run of points of the same voxel, 32-bit in-wave form (at most 256 points).
-struct Run32 {
-    uint32_t key;       // leaf id << 19 | cell, KEY_EMPTY = none
-    int qx, qy, qz;     // fixed-point offsets inside the voxel
-    uint32_t cr;        // count << 16 | sum r
-    uint32_t gb;        // sum g << 16 | sum b
-    uint32_t tile;
-};
 
 // ---------------------------------------------------------------------------
 // global side: leaf lookup, record updates
 // ---------------------------------------------------------------------------
-// Wave-uniform: returns the id (hash position) of leaf key k, inserting it if new.
+// One lane: returns the id (hash position) of leaf key k, inserting it if new.
 __device__ __forceinline__ uint32_t leaf_lookup(const VoxWork &W, uint32_t mask, unsigned long long k) {
     uint32_t pos = (uint32_t)mix64(k) & mask;
     for (uint32_t probe = 0; probe <= mask; probe++) {
@@ -193,282 +202,349 @@ __device__ __forceinline__ uint32_t leaf_lookup(const VoxWork &W, uint32_t mask,
     return 0xffffffffu;
 }
 
-__device__ __forceinline__ void note_first_touch(const VoxWork &W, const VoxParams &P, uint32_t key) {
-    uint32_t idx = atomicAdd(&W.ctrl[C_COUNT], 1u);
-    if (idx < P.list_cap) W.occupied[idx] = key;
-    else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
-}
-
 // Record of voxel key = leaf id << 19 | cell  (grids are CELLS records apart, not 2^19).
 __device__ __forceinline__ unsigned long long *record_ptr(const VoxWork &W, uint32_t key) {
     return W.records + ((size_t)(key >> CELL_BITS) * CELLS + (key & ((1u << CELL_BITS) - 1))) * RECORD_WORDS;
 }
 
-// Slow path (workgroup table saturated): one lane updates a whole record.
-__device__ __forceinline__ void global_insert_lane(const VoxWork &W, const VoxParams &P, uint32_t key, long long sx, long long sy, long long sz,
+// Slow path (workgroup table saturated by incoherent input): one lane updates a whole record.
+__device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t list_cap, uint32_t key, long long sx, long long sy, long long sz,
                                                    unsigned long long cr, unsigned long long gb, uint32_t tile) {
     unsigned long long *rec = record_ptr(W, key);
     atomicAdd(&rec[0], (unsigned long long)sx);
     atomicAdd(&rec[1], (unsigned long long)sy);
     atomicAdd(&rec[2], (unsigned long long)sz);
-    unsigned long long old = atomicAdd(&rec[3], cr);
+    const unsigned long long old = atomicAdd(&rec[3], cr);
     atomicAdd(&rec[4], gb);
     atomicOr(&rec[7], (unsigned long long)tile);
-    if ((old >> 32) == 0) note_first_touch(W, P, key);
+    if ((old >> 32) == 0) {
+        const uint32_t idx = atomicAdd(&W.ctrl[C_COUNT], 1u);
+        if (idx < list_cap) W.occupied[idx] = key;
+        else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+    }
 }
 
 // ---------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------
+// One run of points of the same voxel, 32-bit in-wave form (at most 256 points).
+struct Run32 {
+    uint32_t key;       // leaf id << 19 | cell, KEY_EMPTY = none
+    int qx, qy, qz;     // fixed-point offsets inside the voxel
+    uint32_t cr;        // count << 16 | sum r
+    uint32_t gb;        // sum g << 16 | sum b
+    uint32_t tile;
+};
+
+// Workgroup table entry, 4 packed 64-bit sums.  A workgroup sees fewer than 65536 points, so
+// count < 2^16, colour sums < 2^24, and a biased offset sum < 2^40.
 struct LdsTable {
     uint32_t key[LTAB];
     uint32_t tile[LTAB];
-    unsigned long long sx[LTAB], sy[LTAB], sz[LTAB], cr[LTAB], gb[LTAB];
-    uint32_t fresh[LTAB];      // records this workgroup touched first (appended to the occupied list in one go)
+    unsigned long long a[LTAB];   // sum (qx + bias)
+    unsigned long long b[LTAB];   // sum (qy + bias)
+    unsigned long long c[LTAB];   // sum (qz + bias) | sum b << 40
+    unsigned long long d[LTAB];   // count | sum r << 16 | sum g << 40
+    uint32_t fresh[LTAB];         // records this workgroup touched first
+    float faces[3 * FACES];
     uint32_t nfresh, fresh_base;
 };
 
-__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const VoxParams &P, const Run32 &r) {
+// The slim parameter block of K1 (kernel arguments live in SGPRs; K1 is short of them).
+struct K1Params {
+    uint32_t n, per_wave;
+    float inv_leaf, leaf, fix_scale;
+    int ib0, ib1, ib2;
+    int fb0, fb1, fb2;
+    uint32_t leaf_mask, list_cap, ablate;
+    double mn0[3];      // MODE 2 only
+    double res;
+};
+
+__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32_t list_cap, const Run32 &r) {
     uint32_t slot = (r.key * 0x9E3779B1u) >> (32 - 11);   // LTAB = 2^11
-    const long long sx = r.qx, sy = r.qy, sz = r.qz;
-    const unsigned long long cr = ((unsigned long long)(r.cr >> 16) << 32) | (r.cr & 0xffffu);
-    const unsigned long long gb = ((unsigned long long)(r.gb >> 16) << 32) | (r.gb & 0xffffu);
+    const unsigned long long cnt = r.cr >> 16, rs = r.cr & 0xffffu, gs = r.gb >> 16, bs = r.gb & 0xffffu;
+    const unsigned long long bias = cnt * Q_BIAS;
+    const unsigned long long A = (unsigned long long)((long long)r.qx + (long long)bias);
+    const unsigned long long B = (unsigned long long)((long long)r.qy + (long long)bias);
+    const unsigned long long C = (unsigned long long)((long long)r.qz + (long long)bias) | (bs << 40);
+    const unsigned long long D = cnt | (rs << 16) | (gs << 40);
     for (int probe = 0; probe < LTAB_PROBES; probe++) {
-        uint32_t old = atomicCAS(&L.key[slot], KEY_EMPTY, r.key);
+        const uint32_t old = atomicCAS(&L.key[slot], KEY_EMPTY, r.key);
         if (old == KEY_EMPTY || old == r.key) {
-            atomicAdd(&L.sx[slot], (unsigned long long)sx);
-            atomicAdd(&L.sy[slot], (unsigned long long)sy);
-            atomicAdd(&L.sz[slot], (unsigned long long)sz);
-            atomicAdd(&L.cr[slot], cr);
-            atomicAdd(&L.gb[slot], gb);
+            atomicAdd(&L.a[slot], A);
+            atomicAdd(&L.b[slot], B);
+            atomicAdd(&L.c[slot], C);
+            atomicAdd(&L.d[slot], D);
             atomicOr(&L.tile[slot], r.tile);
             return;
         }
         slot = (slot + 1) & (LTAB - 1);
     }
-    global_insert_lane(W, P, r.key, sx, sy, sz, cr, gb, r.tile);
+    global_insert_lane(W, list_cap, r.key, r.qx, r.qy, r.qz, (cnt << 32) | rs, (gs << 32) | bs, r.tile);
 }
 
-// DPP row shift right by N lanes inside rows of 16 (lanes whose source is outside the row read 0).
+// DPP row shifts inside rows of 16 lanes (lanes whose source is outside the row read 0).
 template <int N>
-__device__ __forceinline__ int dpp_shr(int v) {
+__device__ __forceinline__ int dpp_shr(int v) {   // lane l reads lane l - N
     return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
 }
 template <int N>
-__device__ __forceinline__ int dpp_shl(int v) {
+__device__ __forceinline__ int dpp_shl(int v) {   // lane l reads lane l + N
     return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xf, 0xf, true);
 }
 
+// one step of the segmented inclusive scan (branch-free: a set flag masks the incoming value)
 template <int N>
 __device__ __forceinline__ void scan_step(Run32 &v, int &flag) {
-    const int pqx = dpp_shr<N>(v.qx), pqy = dpp_shr<N>(v.qy), pqz = dpp_shr<N>(v.qz);
-    const int pcr = dpp_shr<N>((int)v.cr), pgb = dpp_shr<N>((int)v.gb), pt = dpp_shr<N>((int)v.tile);
-    const int pf = dpp_shr<N>(flag);
-    if (!flag) {
-        v.qx += pqx; v.qy += pqy; v.qz += pqz;
-        v.cr += (uint32_t)pcr; v.gb += (uint32_t)pgb; v.tile |= (uint32_t)pt;
-    }
-    flag |= pf;
+    const int keep = flag ? 0 : -1;
+    v.qx += dpp_shr<N>(v.qx) & keep;
+    v.qy += dpp_shr<N>(v.qy) & keep;
+    v.qz += dpp_shr<N>(v.qz) & keep;
+    v.cr += (uint32_t)(dpp_shr<N>((int)v.cr) & keep);
+    v.gb += (uint32_t)(dpp_shr<N>((int)v.gb) & keep);
+    v.tile |= (uint32_t)(dpp_shr<N>((int)v.tile) & keep);
+    flag |= dpp_shr<N>(flag);
 }
 
-__global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(VoxParams P, const float *__restrict__ x, const float *__restrict__ y,
+struct PointOut {
+    uint32_t key;   // cell inside the leaf grid, KEY_EMPTY if the point is skipped
+    int l0, l1, l2; // leaf lattice coordinates
+    int q0, q1, q2; // fixed-point offsets
+};
+
+// MODE 0: plain grid (bricks on the voxel lattice); 1: octree leaves by threshold table; 2: octree leaves by f64 division.
+// Branch-free: `good` collects validity, `err` the error bits of this lane.
+template <int MODE>
+__device__ __forceinline__ void axis_cell(const K1Params &P, const float *faces, int ib, int fb, int axis, float f, bool &good, bool &huge,
+                                          bool &off_table, int &l, int &c, int &q) {
+    float g = floorf(__fmul_rn(f, P.inv_leaf));   // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
+    const bool in = fabsf(g) < 33554432.0f;       // false for NaN / Inf / absurdly far points
+    good &= in;
+    huge |= !in && fabsf(f) < INFINITY;           // finite but out of range: an error, not a skipped point
+    g = fminf(fmaxf(g, -33554432.0f), 33554432.0f);
+    const int t = (int)g - ib;
+    if (MODE == 0) {
+        l = t >> 6;
+    } else if (MODE == 1) {
+        const int m = (t + 32) >> 6;                    // the leaf face nearest to this voxel
+        const unsigned i = (unsigned)(m - fb);
+        const bool oob = i >= (unsigned)FACES;
+        off_table |= oob;
+        const float T = faces[axis * FACES + (oob ? 0u : i)];
+        l = m - (f < T ? 1 : 0);
+    } else {
+        l = (int)floor(((double)f - P.mn0[axis]) / P.res);   // genOctreeKeyforPoint
+    }
+    c = t - 64 * l + 2;
+    good &= (unsigned)c < (unsigned)GRID_DIM;
+    // offset inside the voxel in 2^-22 voxel units; one rounding each (fma, product, convert)
+    q = (int)rintf(__fmul_rn(fmaf(-g, P.leaf, f), P.fix_scale));
+}
+
+template <int MODE>
+__device__ __forceinline__ PointOut point_key(const K1Params &P, const float *faces, float fx, float fy, float fz, bool present, uint32_t &err,
+                                              float &bn0, float &bn1, float &bn2, float &bx0, float &bx1, float &bx2) {
+    PointOut o;
+    bool good = present, huge = false, off_table = false;
+    int c0, c1, c2;
+    axis_cell<MODE>(P, faces, P.ib0, P.fb0, 0, fx, good, huge, off_table, o.l0, c0, o.q0);
+    axis_cell<MODE>(P, faces, P.ib1, P.fb1, 1, fy, good, huge, off_table, o.l1, c1, o.q1);
+    axis_cell<MODE>(P, faces, P.ib2, P.fb2, 2, fz, good, huge, off_table, o.l2, c2, o.q2);
+    // the octree skips non-finite points (addPointsFromInputCloud: isFinite); they do not enter the boxes either
+    const bool finite = present && fabsf(fx) < INFINITY && fabsf(fy) < INFINITY && fabsf(fz) < INFINITY;
+    bn0 = fminf(bn0, finite ? fx : FLT_MAX); bx0 = fmaxf(bx0, finite ? fx : -FLT_MAX);
+    bn1 = fminf(bn1, finite ? fy : FLT_MAX); bx1 = fmaxf(bx1, finite ? fy : -FLT_MAX);
+    bn2 = fminf(bn2, finite ? fz : FLT_MAX); bx2 = fmaxf(bx2, finite ? fz : -FLT_MAX);
+    if (MODE == 1) {
+        err |= (finite && off_table && !huge) ? ERR_FACE_TABLE : 0u;
+        good &= !off_table;
+    }
+    err |= (finite && (huge || (!good && !off_table))) ? ERR_RANGE : 0u;
+    o.key = (good && finite) ? (uint32_t)((c2 * GRID_DIM + c1) * GRID_DIM + c0) : KEY_EMPTY;
+    return o;
+}
+
+__device__ __forceinline__ void add_point(Run32 &r, const PointOut &o, uint32_t w) {
+    r.qx += o.q0; r.qy += o.q1; r.qz += o.q2;
+    r.cr += (1u << 16) | (w & 0xffu);
+    r.gb += (((w >> 8) & 0xffu) << 16) | ((w >> 16) & 0xffu);
+    r.tile |= w >> 24;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P, const float *__restrict__ x, const float *__restrict__ y,
                                                                      const float *__restrict__ z, const uint32_t *__restrict__ rgbt, VoxWork W) {
     extern __shared__ __align__(16) unsigned char k1_smem[];
     LdsTable &L = *reinterpret_cast<LdsTable *>(k1_smem);
 
     for (int i = threadIdx.x; i < LTAB; i += K1_THREADS) {
         L.key[i] = KEY_EMPTY; L.tile[i] = 0;
-        L.sx[i] = 0; L.sy[i] = 0; L.sz[i] = 0; L.cr[i] = 0; L.gb[i] = 0;
+        L.a[i] = 0; L.b[i] = 0; L.c[i] = 0; L.d[i] = 0;
+    }
+    if (MODE == 1) {
+        for (int i = threadIdx.x; i < 3 * FACES; i += K1_THREADS) L.faces[i] = W.faces[i];
     }
     if (threadIdx.x == 0) L.nfresh = 0;
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const uint32_t range = blockIdx.x * K1_WAVES + (threadIdx.x >> 6);
+    float bn0 = FLT_MAX, bn1 = FLT_MAX, bn2 = FLT_MAX, bx0 = -FLT_MAX, bx1 = -FLT_MAX, bx2 = -FLT_MAX;
+    uint32_t err = 0;
+    // this wave's range [lo, hi); planes are padded to a multiple of 256 points, so whole steps can be loaded
+    const uint32_t lo = range * P.per_wave;
+    const uint32_t hi = min(lo + P.per_wave, P.n);
+    const int npts = lo < hi ? (int)(hi - lo) : 0;
+    const float4 *vx = reinterpret_cast<const float4 *>(x + lo) + lane;
+    const float4 *vy = reinterpret_cast<const float4 *>(y + lo) + lane;
+    const float4 *vz = reinterpret_cast<const float4 *>(z + lo) + lane;
+    const uint4 *vw = reinterpret_cast<const uint4 *>(rgbt + lo) + lane;
 
-    // Anchor: the first point (octree lattice phase).
-    const float p0x = x[0], p0y = y[0], p0z = z[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !(isfinite(p0x) && isfinite(p0y) && isfinite(p0z))) atomicOr(&W.ctrl[C_ERR], ERR_FIRST_POINT);
-    const Anchor A = make_anchor(P, p0x, p0y, p0z);
-    __syncthreads();
-
-    float bmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, bmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    const size_t lo = (size_t)range * P.per_wave;
-    const size_t hi = lo + P.per_wave < P.n ? lo + P.per_wave : P.n;
-
-    // wave-uniform leaf cache
-    unsigned long long cache_key = 0;
+    // wave-uniform cache of the last leaf and its id
+    int cl0 = 0, cl1 = 0, cl2 = 0;
     uint32_t cache_id = 0xffffffffu;
+    bool cache_valid = false;
+
+    float4 cx = make_float4(0, 0, 0, 0), cy = cx, cz = cx;
+    uint4 cw = make_uint4(0, 0, 0, 0);
+    if (npts > 0) { cx = vx[0]; cy = vy[0]; cz = vz[0]; cw = vw[0]; }
 
 #pragma unroll 1
-    for (size_t base = lo; base < hi; base += WAVE_STEP) {
-        const size_t p = base + (size_t)lane * 4;
-        float px[4], py[4], pz[4];
-        uint32_t pw[4];
-        int cnt = 0;
-        if (p + 4 <= hi) {
-            const float4 a = *(const float4 *)(x + p), b = *(const float4 *)(y + p), c = *(const float4 *)(z + p);
-            const uint4 w = *(const uint4 *)(rgbt + p);
-            px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w;
-            py[0] = b.x; py[1] = b.y; py[2] = b.z; py[3] = b.w;
-            pz[0] = c.x; pz[1] = c.y; pz[2] = c.z; pz[3] = c.w;
-            pw[0] = w.x; pw[1] = w.y; pw[2] = w.z; pw[3] = w.w;
-            cnt = 4;
-        } else {
-            cnt = p < hi ? (int)(hi - p) : 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool ok = j < cnt;
-                px[j] = ok ? x[p + j] : 0.f;
-                py[j] = ok ? y[p + j] : 0.f;
-                pz[j] = ok ? z[p + j] : 0.f;
-                pw[j] = ok ? rgbt[p + j] : 0u;
-            }
+    for (int off = 0; off < npts; off += WAVE_STEP) {
+        // keep the next step's 64 bytes per lane in flight while this step is processed
+        float4 nx = cx, ny = cy, nz = cz;
+        uint4 nw = cw;
+        if (off + WAVE_STEP < npts) {
+            const int v = (off + WAVE_STEP) >> 2;
+            nx = vx[v]; ny = vy[v]; nz = vz[v]; nw = vw[v];
+        }
+        const int left = npts - off - lane * 4;   // points of this lane that exist: min(left, 4)
+
+        if (P.ablate & 1u) {   // diagnostics: loads only
+            bn0 = fminf(bn0, cx.x + cx.y + cx.z + cx.w + cy.x + cy.y + cy.z + cy.w + cz.x + cz.y + cz.z + cz.w + __uint_as_float(cw.x ^ cw.y ^ cw.z ^ cw.w));
+            cx = nx; cy = ny; cz = nz; cw = nw;
+            continue;
         }
 
-        // ---- per point: cell inside its leaf, leaf lattice coordinates, fixed-point offsets ----
-        uint32_t key[4];
-        unsigned long long lkey[4];
-        int qx[4], qy[4], qz[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            key[j] = KEY_EMPTY;
-            lkey[j] = 0;
-            qx[j] = qy[j] = qz[j] = 0;
-            const float f[3] = {px[j], py[j], pz[j]};
-            if (j < cnt && isfinite(f[0]) && isfinite(f[1]) && isfinite(f[2])) {
-                int cell[3], leaf[3], q[3];
-                bool bad = false;
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    bmin[a] = fminf(bmin[a], f[a]);
-                    bmax[a] = fmaxf(bmax[a], f[a]);
-                    // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
-                    const float g = floorf(__fmul_rn(f[a], P.inv_leaf));
-                    bad |= !(fabsf(g) < 67108864.0f);
-                    const int v = (int)g;
-                    const int t = v - A.ib[a];
-                    int l;
-                    if (!P.leaf_split) {
-                        l = t >> 6;
-                    } else if (((t - 2) >> 6) == ((t + 2) >> 6)) {
-                        l = t >> 6;   // the voxel is not near a leaf face: its leaf follows from its index
-                    } else {
-                        // genOctreeKeyforPoint: floor((p - min) / resolution) in double
-                        l = (int)floor(((double)f[a] - A.mn0[a]) / P.res);
+        // ---- per point: cell, leaf lattice coordinates, fixed-point offsets (branch-free) ----
+        PointOut o0 = point_key<MODE>(P, L.faces, cx.x, cy.x, cz.x, left > 0, err, bn0, bn1, bn2, bx0, bx1, bx2);
+        PointOut o1 = point_key<MODE>(P, L.faces, cx.y, cy.y, cz.y, left > 1, err, bn0, bn1, bn2, bx0, bx1, bx2);
+        PointOut o2 = point_key<MODE>(P, L.faces, cx.z, cy.z, cz.z, left > 2, err, bn0, bn1, bn2, bx0, bx1, bx2);
+        PointOut o3 = point_key<MODE>(P, L.faces, cx.w, cy.w, cz.w, left > 3, err, bn0, bn1, bn2, bx0, bx1, bx2);
+
+        if (P.ablate & 2u) {   // diagnostics: loads + per-point arithmetic only
+            bx0 = fmaxf(bx0, __uint_as_float((o0.key ^ o1.key ^ o2.key ^ o3.key) + (uint32_t)(o0.q0 + o1.q1 + o2.q2 + o3.q0 + o0.l0 + o1.l1 + o2.l2)));
+            cx = nx; cy = ny; cz = nz; cw = nw;
+            continue;
+        }
+
+        // ---- leaf ids ----
+        {
+            int mism = 0;
+            mism |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
+            mism |= o1.key != KEY_EMPTY ? (o1.l0 ^ cl0) | (o1.l1 ^ cl1) | (o1.l2 ^ cl2) : 0;
+            mism |= o2.key != KEY_EMPTY ? (o2.l0 ^ cl0) | (o2.l1 ^ cl1) | (o2.l2 ^ cl2) : 0;
+            mism |= o3.key != KEY_EMPTY ? (o3.l0 ^ cl0) | (o3.l1 ^ cl1) | (o3.l2 ^ cl2) : 0;
+            if (cache_valid && __ballot(mism != 0) == 0ull) {
+                // the whole step lies in the cached leaf (the common case); KEY_EMPTY stays all ones
+                const uint32_t hi_bits = cache_id << CELL_BITS;
+                o0.key |= hi_bits; o1.key |= hi_bits; o2.key |= hi_bits; o3.key |= hi_bits;
+            } else {
+                // general case: resolve the distinct leaves of this step one at a time
+                unsigned pend = (o0.key != KEY_EMPTY ? 1u : 0u) | (o1.key != KEY_EMPTY ? 2u : 0u) | (o2.key != KEY_EMPTY ? 4u : 0u) |
+                                (o3.key != KEY_EMPTY ? 8u : 0u);
+                for (;;) {
+                    const unsigned long long need = __ballot(pend != 0u);
+                    if (!need) break;
+                    const int src = __ffsll((long long)need) - 1;
+                    const int slot = __ffs((int)pend) - 1;   // meaningful in lane src
+                    const int m0 = slot == 0 ? o0.l0 : slot == 1 ? o1.l0 : slot == 2 ? o2.l0 : o3.l0;
+                    const int m1 = slot == 0 ? o0.l1 : slot == 1 ? o1.l1 : slot == 2 ? o2.l1 : o3.l1;
+                    const int m2 = slot == 0 ? o0.l2 : slot == 1 ? o1.l2 : slot == 2 ? o2.l2 : o3.l2;
+                    const int s0 = __builtin_amdgcn_readlane(m0, src), s1 = __builtin_amdgcn_readlane(m1, src), s2 = __builtin_amdgcn_readlane(m2, src);
+                    if (!(cache_valid && s0 == cl0 && s1 == cl1 && s2 == cl2)) {
+                        uint32_t found = 0;
+                        if (lane == src) found = leaf_lookup(W, P.leaf_mask, pack_leaf(s0, s1, s2));
+                        cache_id = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
+                        cl0 = s0; cl1 = s1; cl2 = s2;
+                        cache_valid = true;
                     }
-                    leaf[a] = l;
-                    cell[a] = t - 64 * l + 2;
-                    bad |= (unsigned)cell[a] >= (unsigned)GRID_DIM || l < -1048576 || l > 1048575;
-                    // offset inside the voxel in 2^-22 voxel units; single rounding each (fma, product, convert)
-                    q[a] = (int)rintf(__fmul_rn(fmaf(-g, P.leaf, f[a]), P.fix_scale));
-                }
-                if (bad) {
-                    atomicOr(&W.ctrl[C_ERR], ERR_RANGE);
-                } else {
-                    key[j] = (uint32_t)((cell[2] * GRID_DIM + cell[1]) * GRID_DIM + cell[0]);
-                    lkey[j] = pack_leaf(leaf[0], leaf[1], leaf[2]);
-                    qx[j] = q[0]; qy[j] = q[1]; qz[j] = q[2];
+                    const uint32_t hi_bits = cache_id << CELL_BITS;
+                    const bool lost = cache_id == 0xffffffffu;
+                    if ((pend & 1u) && o0.l0 == s0 && o0.l1 == s1 && o0.l2 == s2) { pend &= ~1u; o0.key = lost ? KEY_EMPTY : (o0.key | hi_bits); }
+                    if ((pend & 2u) && o1.l0 == s0 && o1.l1 == s1 && o1.l2 == s2) { pend &= ~2u; o1.key = lost ? KEY_EMPTY : (o1.key | hi_bits); }
+                    if ((pend & 4u) && o2.l0 == s0 && o2.l1 == s1 && o2.l2 == s2) { pend &= ~4u; o2.key = lost ? KEY_EMPTY : (o2.key | hi_bits); }
+                    if ((pend & 8u) && o3.l0 == s0 && o3.l1 == s1 && o3.l2 == s2) { pend &= ~8u; o3.key = lost ? KEY_EMPTY : (o3.key | hi_bits); }
                 }
             }
         }
 
-        // ---- leaf ids: wave-uniform lookups (a wave sees one or two leaves per step) ----
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            unsigned long long pending = lkey[j];
-            for (;;) {
-                const unsigned long long need = __ballot(pending != 0ull);
-                if (!need) break;
-                const int src = __ffsll((long long)need) - 1;
-                const unsigned long long k = ((unsigned long long)(uint32_t)__shfl((int)(pending >> 32), src, 64) << 32) |
-                                             (uint32_t)__shfl((int)(uint32_t)pending, src, 64);
-                if (k != cache_key) {
-                    uint32_t id = 0;
-                    if (lane == src) id = leaf_lookup(W, P.leaf_mask, k);
-                    cache_id = (uint32_t)__shfl((int)id, src, 64);
-                    cache_key = k;
-                }
-                if (pending == k) {
-                    pending = 0ull;
-                    key[j] = cache_id == 0xffffffffu ? KEY_EMPTY : (key[j] | (cache_id << CELL_BITS));
-                }
-            }
-        }
-
-        // ---- lane-local runs; lanes whose 4 points share one voxel take part in the wave merge ----
-        const bool uniform = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
-        const bool single = uniform && key[0] != KEY_EMPTY;
+        // ---- runs of this lane; lanes whose 4 points share one voxel take part in the wave merge ----
+        const int ri1 = o1.key != o0.key ? 1 : 0;
+        const int ri2 = ri1 + (o2.key != o1.key ? 1 : 0);
+        const int ri3 = ri2 + (o3.key != o2.key ? 1 : 0);
+        const int nruns = ri3 + 1;
+        const bool single = nruns == 1 && o0.key != KEY_EMPTY;
         Run32 v;
-        v.key = single ? key[0] : KEY_EMPTY;
+        v.key = single ? o0.key : KEY_EMPTY;
         v.qx = v.qy = v.qz = 0;
         v.cr = v.gb = v.tile = 0;
-        if (single) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                v.qx += qx[j]; v.qy += qy[j]; v.qz += qz[j];
-                v.cr += (1u << 16) | (pw[j] & 0xffu);
-                v.gb += (((pw[j] >> 8) & 0xffu) << 16) | ((pw[j] >> 16) & 0xffu);
-                v.tile |= pw[j] >> 24;
-            }
-        }
-        // segmented inclusive scan over chains of consecutive single lanes with equal keys, inside rows of 16 lanes
+        add_point(v, o0, cw.x); add_point(v, o1, cw.y); add_point(v, o2, cw.z); add_point(v, o3, cw.w);
+        const int smask = single ? -1 : 0;   // lanes with several voxels contribute nothing to the merge
+        v.qx &= smask; v.qy &= smask; v.qz &= smask;
+        v.cr &= (uint32_t)smask; v.gb &= (uint32_t)smask; v.tile &= (uint32_t)smask;
+        // segmented inclusive scan over chains of consecutive single lanes with equal keys; chains are
+        // cut every 8 lanes so that three DPP steps (1, 2, 4) cover them completely
         const int prev_key = dpp_shr<1>((int)v.key);
-        int flag = (!single || (lane & 15) == 0 || (uint32_t)prev_key != v.key) ? 1 : 0;
+        int flag = (!single || (lane & 7) == 0 || (uint32_t)prev_key != v.key) ? 1 : 0;
         scan_step<1>(v, flag);
         scan_step<2>(v, flag);
         scan_step<4>(v, flag);
-        scan_step<8>(v, flag);
         // a chain ends where the next lane does not continue it
         const int next_key = dpp_shl<1>((int)v.key);
-        const bool chain_end = single && ((lane & 15) == 15 || (uint32_t)next_key != v.key);
-        if (chain_end) lds_insert(L, W, P, v);
+        const bool chain_end = single && ((lane & 7) == 7 || (uint32_t)next_key != v.key);
 
-        // lanes with several voxels among their 4 points insert their runs directly
-        if (__ballot(!uniform)) {
-            if (!uniform) {
+        // ---- insert rounds: round k carries run k of every lane (round 0: chain ends of merged lanes) ----
+        if (!(P.ablate & 4u)) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                if (k > 0 && __ballot(!single && nruns > k) == 0ull) break;
                 Run32 r;
                 r.key = KEY_EMPTY;
                 r.qx = r.qy = r.qz = 0;
                 r.cr = r.gb = r.tile = 0;
-#pragma unroll 1
-                for (int j = 0; j <= 4; j++) {
-                    uint32_t kj = KEY_EMPTY, wj = 0;
-                    int ax = 0, ay = 0, az = 0;
-                    if (j < 4) {
-                        kj = j == 0 ? key[0] : j == 1 ? key[1] : j == 2 ? key[2] : key[3];
-                        wj = j == 0 ? pw[0] : j == 1 ? pw[1] : j == 2 ? pw[2] : pw[3];
-                        ax = j == 0 ? qx[0] : j == 1 ? qx[1] : j == 2 ? qx[2] : qx[3];
-                        ay = j == 0 ? qy[0] : j == 1 ? qy[1] : j == 2 ? qy[2] : qy[3];
-                        az = j == 0 ? qz[0] : j == 1 ? qz[1] : j == 2 ? qz[2] : qz[3];
-                    }
-                    if (kj != r.key) {
-                        if (r.key != KEY_EMPTY) lds_insert(L, W, P, r);
-                        r.key = kj;
-                        r.qx = r.qy = r.qz = 0;
-                        r.cr = r.gb = r.tile = 0;
-                    }
-                    if (kj != KEY_EMPTY) {
-                        r.qx += ax; r.qy += ay; r.qz += az;
-                        r.cr += (1u << 16) | (wj & 0xffu);
-                        r.gb += (((wj >> 8) & 0xffu) << 16) | ((wj >> 16) & 0xffu);
-                        r.tile |= wj >> 24;
-                    }
+                if (k == 0) { r.key = o0.key; add_point(r, o0, cw.x); }
+                if (k == ri1) { r.key = o1.key; add_point(r, o1, cw.y); }
+                if (k == ri2) { r.key = o2.key; add_point(r, o2, cw.z); }
+                if (k == ri3) { r.key = o3.key; add_point(r, o3, cw.w); }
+                bool act = k < nruns && r.key != KEY_EMPTY;
+                if (single) {
+                    r = v;
+                    act = chain_end && k == 0;
                 }
+                if (act) lds_insert(L, W, P.list_cap, r);
             }
         }
+        cx = nx; cy = ny; cz = nz; cw = nw;
     }
 
-    // ---- bounding box of this wave's range (input of the octree replay) ----
+    // ---- errors of this wave, bounding box of its range (input of the octree replay) ----
+    {
+        for (int s = 32; s > 0; s >>= 1) err |= (uint32_t)__shfl_xor((int)err, s, 64);
+        if (lane == 0 && err) atomicOr(&W.ctrl[C_ERR], err);
+        const float lo3[3] = {bn0, bn1, bn2}, hi3[3] = {bx0, bx1, bx2};
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-        float vlo = bmin[a], vhi = bmax[a];
-        for (int off = 32; off > 0; off >>= 1) {
-            vlo = fminf(vlo, __shfl_down(vlo, off, 64));
-            vhi = fmaxf(vhi, __shfl_down(vhi, off, 64));
-        }
-        if (lane == 0) {
-            W.bboxes[(size_t)range * 6 + a] = vlo;
-            W.bboxes[(size_t)range * 6 + 3 + a] = vhi;
+        for (int a = 0; a < 3; a++) {
+            float vlo = lo3[a], vhi = hi3[a];
+            for (int s = 32; s > 0; s >>= 1) {
+                vlo = fminf(vlo, __shfl_down(vlo, s, 64));
+                vhi = fmaxf(vhi, __shfl_down(vhi, s, 64));
+            }
+            if (lane == 0) {
+                W.bboxes[(size_t)range * 6 + a] = vlo;
+                W.bboxes[(size_t)range * 6 + 3 + a] = vhi;
+            }
         }
     }
 
@@ -478,15 +554,17 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(VoxParams 
 #pragma unroll 1
     for (int e = threadIdx.x >> 3; e < LTAB; e += K1_THREADS / 8) {
         const uint32_t k = L.key[e];
-        if (k == KEY_EMPTY) continue;
+        if (k == KEY_EMPTY || (P.ablate & 8u)) continue;
         const uint32_t t = L.tile[e];
+        const unsigned long long ea = L.a[e], eb = L.b[e], ec = L.c[e], ed = L.d[e];
+        const unsigned long long cnt = ed & 0xffffull, bias = cnt * Q_BIAS;
         unsigned long long val;
         switch (sub) {
-        case 0: val = L.sx[e]; break;
-        case 1: val = L.sy[e]; break;
-        case 2: val = L.sz[e]; break;
-        case 3: val = L.cr[e]; break;
-        case 4: val = L.gb[e]; break;
+        case 0: val = ea - bias; break;                                      // sum qx (two's complement)
+        case 1: val = eb - bias; break;
+        case 2: val = (ec & ((1ull << 40) - 1)) - bias; break;
+        case 3: val = (cnt << 32) | ((ed >> 16) & 0xffffffull); break;      // count << 32 | sum r
+        case 4: val = ((ed >> 40) << 32) | (ec >> 40); break;               // sum g << 32 | sum b
         case 5:   // tile bits 0-3 as 16-bit contribution counters
             val = (unsigned long long)(t & 1u) | ((unsigned long long)((t >> 1) & 1u) << 16) | ((unsigned long long)((t >> 2) & 1u) << 32) |
                   ((unsigned long long)((t >> 3) & 1u) << 48);
@@ -499,8 +577,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(VoxParams 
         }
         unsigned long long *rec = record_ptr(W, k);
         const unsigned long long old = atomicAdd(&rec[sub], val);
-        // One global counter bumped by every first toucher would serialise ~40 k same-address
-        // atomics at the memory side; collect them per workgroup instead.
         if (sub == 3 && (old >> 32) == 0) L.fresh[atomicAdd(&L.nfresh, 1u)] = k;
     }
     __syncthreads();
@@ -570,12 +646,8 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
     }
 
     if (tid == 0) {
-        double pp[3] = {(double)x[0], (double)y[0], (double)z[0]};
-        double mn[3], mx[3];
-        int d;
-        first_box(pp, P.res, mn, mx, d);
-        for (int a = 0; a < 3; a++) { s_mn[a] = mn[a]; s_mx[a] = mx[a]; s_shift[a] = 0; }
-        s_depth = d;
+        for (int a = 0; a < 3; a++) { s_mn[a] = P.mn0[a]; s_mx[a] = P.mx0[a]; s_shift[a] = 0; }
+        s_depth = P.depth0;
         s_events = 0;
     }
     __syncthreads();
@@ -680,8 +752,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
 // ---------------------------------------------------------------------------
 // positive cellsize: [ Morton code of the leaf's final octree key | k | j | i inside the leaf ]
 // negative cellsize: pcl::VoxelGrid's idx = i + j*div_x + k*div_x*div_y
-__global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWork W, const float *__restrict__ x, const float *__restrict__ y,
-                                                            const float *__restrict__ z, uint32_t m, unsigned long long *__restrict__ sort_keys,
+__global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWork W, uint32_t m, unsigned long long *__restrict__ sort_keys,
                                                             uint32_t *__restrict__ sort_vals) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
@@ -691,9 +762,8 @@ __global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWor
     const unsigned long long lp = W.leaf_keys[leaf_id];
     unsigned long long sk;
     if (!P.leaf_split) {
-        const Anchor A = make_anchor(P, 0.f, 0.f, 0.f);
         long long d[3];
-        for (int a = 0; a < 3; a++) d[a] = (long long)(c[a] + A.ib[a] + 64 * unpack_leaf(lp, a) - 2) - (long long)(int)W.ctrl[C_MINB + a];
+        for (int a = 0; a < 3; a++) d[a] = (long long)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2) - (long long)(int)W.ctrl[C_MINB + a];
         const long long dx = (int)W.ctrl[C_DIVB], dy = (int)W.ctrl[C_DIVB + 1];
         sk = (unsigned long long)(d[0] + d[1] * dx + d[2] * dx * dy);
     } else {
@@ -724,8 +794,7 @@ __global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWor
 // ---------------------------------------------------------------------------
 // K4: emit in output order and clean the records
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWork W, const float *__restrict__ x, const float *__restrict__ y,
-                                                            const float *__restrict__ z, uint32_t m, const uint32_t *__restrict__ sorted_keys,
+__global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWork W, uint32_t m, const uint32_t *__restrict__ sorted_keys,
                                                             float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
                                                             uint32_t *__restrict__ ow, int emit) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -737,9 +806,8 @@ __global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWor
         const uint32_t cell = key & ((1u << CELL_BITS) - 1), leaf_id = key >> CELL_BITS;
         const int c[3] = {(int)(cell % GRID_DIM), (int)((cell / GRID_DIM) % GRID_DIM), (int)(cell / (GRID_DIM * GRID_DIM))};
         const unsigned long long lp = W.leaf_keys[leaf_id];
-        const Anchor A = make_anchor(P, x[0], y[0], z[0]);
         double vox[3];
-        for (int a = 0; a < 3; a++) vox[a] = (double)(c[a] + A.ib[a] + 64 * unpack_leaf(lp, a) - 2);
+        for (int a = 0; a < 3; a++) vox[a] = (double)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2);
         const unsigned long long cr = w23.y, gb = w45.x;
         const uint32_t cnt = (uint32_t)(cr >> 32);
         const double n = (double)cnt, unit = (double)P.fix_scale;
@@ -777,7 +845,9 @@ struct Workspace {
     uint32_t *occupied = nullptr;
     float *bboxes = nullptr;
     uint32_t *ctrl = nullptr;
-    int num_cus = 0;
+    float *faces = nullptr;            // device copy of the threshold table
+    float faces_host[3 * FACES];       // what the device copy holds
+    bool faces_valid = false;
     void release() {
         // also runs at thread exit, when the runtime may be gone: errors ignored
         if (leaf_keys) (void)hipFree(leaf_keys);
@@ -785,8 +855,10 @@ struct Workspace {
         if (occupied) (void)hipFree(occupied);
         if (bboxes) (void)hipFree(bboxes);
         if (ctrl) (void)hipFree(ctrl);
-        leaf_keys = nullptr; records = nullptr; occupied = nullptr; bboxes = nullptr; ctrl = nullptr;
+        if (faces) (void)hipFree(faces);
+        leaf_keys = nullptr; records = nullptr; occupied = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
         leaf_cap = 0; list_cap = 0; bbox_cap = 0;
+        faces_valid = false;
     }
     ~Workspace() { release(); }
 };
@@ -799,11 +871,10 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
     const int dev = current_device();
     if (ws.device != dev) {
         ws.release();
-        hipDeviceProp_t prop;
-        CW_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        ws.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(LdsTable)));
+        const int lds = (int)sizeof(LdsTable);
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ws.device = dev;
     }
     if (ws.leaf_cap < leaf_cap) {
@@ -828,6 +899,21 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         ws.bbox_cap = nranges;
     }
     if (!ws.ctrl) CW_HIP_TRY(hipMalloc((void **)&ws.ctrl, C_WORDS * sizeof(uint32_t)));
+    if (!ws.faces) CW_HIP_TRY(hipMalloc((void **)&ws.faces, 3 * FACES * sizeof(float)));
+    return true;
+}
+
+// The first point of a cloud the host has not seen (a filter result): three 4-byte reads, once per cloud.
+bool fetch_first_point(const DeviceSoA &src, ThreadCtx &c) {
+    if (src.has_first) return true;
+    float *h = (float *)c.host_words;
+    bool ok = hipMemcpyAsync(h, src.x(), 4, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipMemcpyAsync(h + 1, src.y(), 4, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipMemcpyAsync(h + 2, src.z(), 4, hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    ok = c.sync() && ok;
+    if (!ok) return hip_failed(hipGetLastError(), "fetch of the first point", __FILE__, __LINE__);
+    src.first[0] = h[0]; src.first[1] = h[1]; src.first[2] = h[2];
+    src.has_first = true;
     return true;
 }
 
@@ -838,45 +924,106 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     if (!c.ensure()) return nullptr;
     const size_t n = src.npoints;
     Workspace &ws = t_ws;
+    if (n >= ((size_t)1 << 31)) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: more than 2^31 points");
+        return nullptr;
+    }
+
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus <= 0) cus = 256;
+    // one persistent workgroup per CU; short clouds get fewer so that every wave has at least one step,
+    // very large clouds get more (sequential) workgroups: the packed table needs < 65536 points per workgroup
+    size_t nwaves = (size_t)cus * K1_WAVES;
+    const size_t steps_total = (n + WAVE_STEP - 1) / WAVE_STEP;
+    if (nwaves > steps_total) nwaves = ((steps_total + K1_WAVES - 1) / K1_WAVES) * K1_WAVES;
+    const size_t min_waves = (n + MAX_POINTS_PER_WAVE - 1) / MAX_POINTS_PER_WAVE;
+    if (nwaves < min_waves) nwaves = ((min_waves + K1_WAVES - 1) / K1_WAVES) * K1_WAVES;
+    const uint32_t nblocks = (uint32_t)(nwaves / K1_WAVES);
+
+    VoxParams P;
+    memset(&P, 0, sizeof(P));
+    P.n = n;
+    P.per_wave = (((n + nwaves - 1) / nwaves + WAVE_STEP - 1) / WAVE_STEP) * WAVE_STEP;
+    P.nranges = (uint32_t)nwaves;
+    P.leaf = cellsize;
+    P.inv_leaf = 1.0f / cellsize;
+    P.fix_scale = FIX_ONE_F / cellsize;
+    P.leaf_d = (double)cellsize;
+    const float octree_cellsize = (8 * 8) * cellsize;   // reference src/cwipc_filters.cpp:113-114
+    P.res = (double)octree_cellsize;
+    P.leaf_split = leaf_split ? 1 : 0;
+    const char *ablate = getenv("CWIPC_VOXEL_ABLATE");
+    P.ablate = ablate ? (uint32_t)atoi(ablate) : 0u;
+
+    // ---- anchor and face thresholds (host, f64) ----
+    float faces_host[3 * FACES];
+    memset(faces_host, 0, sizeof(faces_host));
+    if (leaf_split) {
+        if (!fetch_first_point(src, c)) return nullptr;
+        if (!(std::isfinite(src.first[0]) && std::isfinite(src.first[1]) && std::isfinite(src.first[2]))) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the first point of the cloud is not finite");
+            return nullptr;
+        }
+        const double pp[3] = {(double)src.first[0], (double)src.first[1], (double)src.first[2]};
+        first_box(pp, P.res, P.mn0, P.mx0, P.depth0);
+        for (int a = 0; a < 3; a++) {
+            P.ib[a] = (int)floor(P.mn0[a] / P.leaf_d);
+            // the first point sits in leaf 1 of its box: cover faces 1 - FACE_BACK .. 1 - FACE_BACK + FACES - 1
+            P.face_base[a] = 1 - FACE_BACK;
+            for (int i = 0; i < FACES; i++) faces_host[a * FACES + i] = leaf_threshold(P.mn0[a], P.res, P.face_base[a] + i);
+        }
+    } else {
+        for (int a = 0; a < 3; a++) P.ib[a] = 2;   // bricks of 64 voxels aligned to the voxel lattice
+    }
 
     uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 64;   // 64 grids = 1.3 GB; grown x4 when a cloud has more leaves
-    for (int attempt = 0; attempt < 5; attempt++) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus <= 0) cus = 256;
-        // one persistent workgroup per CU; short clouds get fewer so that every wave has at least one step
-        size_t nwaves = (size_t)cus * K1_WAVES;
-        const size_t steps_total = (n + WAVE_STEP - 1) / WAVE_STEP;
-        if (nwaves > steps_total) nwaves = ((steps_total + K1_WAVES - 1) / K1_WAVES) * K1_WAVES;
-        const uint32_t nblocks = (uint32_t)(nwaves / K1_WAVES);
+    int mode = leaf_split ? 1 : 0;
+    for (int attempt = 0; attempt < 6; attempt++) {
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
-
-        VoxParams P;
-        P.n = n;
-        P.per_wave = (((n + nwaves - 1) / nwaves + WAVE_STEP - 1) / WAVE_STEP) * WAVE_STEP;
-        P.nranges = (uint32_t)nwaves;
-        P.leaf = cellsize;
-        P.inv_leaf = 1.0f / cellsize;
-        P.fix_scale = FIX_ONE_F / cellsize;
-        P.leaf_d = (double)cellsize;
-        float octree_cellsize = (8 * 8) * cellsize;   // reference src/cwipc_filters.cpp:113-114
-        P.res = (double)octree_cellsize;
-        P.leaf_split = leaf_split ? 1 : 0;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
-        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes};
+        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces};
 
         bool ok = hipMemsetAsync(ws.ctrl, 0, C_WORDS * sizeof(uint32_t), c.stream) == hipSuccess &&
                   hipMemsetAsync(ws.leaf_keys, 0, (size_t)ws.leaf_cap * 8, c.stream) == hipSuccess;
-        if (!ok) { hip_failed(hipGetLastError(), "hipMemsetAsync(voxel ctrl)", __FILE__, __LINE__); return nullptr; }
+        if (ok && mode == 1 && !(ws.faces_valid && memcmp(ws.faces_host, faces_host, sizeof(faces_host)) == 0)) {
+            float *stage = (float *)c.staging(sizeof(faces_host));
+            ok = stage != nullptr;
+            if (ok) {
+                memcpy(stage, faces_host, sizeof(faces_host));
+                ok = hipMemcpyAsync(ws.faces, stage, sizeof(faces_host), hipMemcpyHostToDevice, c.stream) == hipSuccess;
+                memcpy(ws.faces_host, faces_host, sizeof(faces_host));
+                ws.faces_valid = ok;
+            }
+        }
+        if (!ok) { hip_failed(hipGetLastError(), "voxel workspace setup", __FILE__, __LINE__); return nullptr; }
 
-        CW_LAUNCH("voxel_accumulate", voxel_accumulate_kernel, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, P, src.x(), src.y(),
-                  src.z(), src.rgbt(), W);
+        K1Params K;
+        memset(&K, 0, sizeof(K));
+        K.n = (uint32_t)n; K.per_wave = (uint32_t)P.per_wave;
+        K.inv_leaf = P.inv_leaf; K.leaf = P.leaf; K.fix_scale = P.fix_scale;
+        K.ib0 = P.ib[0]; K.ib1 = P.ib[1]; K.ib2 = P.ib[2];
+        K.fb0 = P.face_base[0]; K.fb1 = P.face_base[1]; K.fb2 = P.face_base[2];
+        K.leaf_mask = P.leaf_mask; K.list_cap = P.list_cap; K.ablate = P.ablate;
+        K.mn0[0] = P.mn0[0]; K.mn0[1] = P.mn0[1]; K.mn0[2] = P.mn0[2];
+        K.res = P.res;
+        if (mode == 0) {
+            CW_LAUNCH("voxel_accumulate", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
+                      src.z(), src.rgbt(), W);
+        } else if (mode == 1) {
+            CW_LAUNCH("voxel_accumulate", voxel_accumulate_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
+                      src.z(), src.rgbt(), W);
+        } else {
+            CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(),
+                      src.y(), src.z(), src.rgbt(), W);
+        }
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl);
         ok = hipMemcpyAsync(c.host_words, ws.ctrl, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
         ok = c.sync() && ok;
         if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
         uint32_t err = c.host_words[C_ERR];
+        const uint32_t depth = c.host_words[C_DEPTH];
         const uint32_t m = c.host_words[C_COUNT] < P.list_cap ? c.host_words[C_COUNT] : P.list_cap;
         std::shared_ptr<DeviceSoA> dst;
         unsigned long long *keys_in = nullptr, *keys_out = nullptr;
@@ -893,12 +1040,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             } else {
                 keys_out = keys_in + m;
                 vals_out = vals_in + m;
-                CW_LAUNCH("make_sort_keys", make_sort_keys_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, src.x(), src.y(), src.z(), m, keys_in,
-                          vals_in);
+                CW_LAUNCH("make_sort_keys", make_sort_keys_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, keys_in, vals_in);
                 // only the bits that can be set take part in the sort
-                unsigned end_bit = 64;
-                if (leaf_split) end_bit = 21 + 3 * c.host_words[C_DEPTH];
-                else end_bit = 32;
+                unsigned end_bit = leaf_split ? 21 + 3 * depth : 32;
                 if (end_bit > 64) end_bit = 64;
                 size_t tmp_bytes = 0;
                 hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)m, 0u, end_bit, c.stream);
@@ -920,8 +1064,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (m) {
             // emit (or, on error, only clean): the records must be left zeroed either way
             const int emit = (!err && dst) ? 1 : 0;
-            CW_LAUNCH("emit_and_clean", emit_and_clean_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, src.x(), src.y(), src.z(), m, vals_out,
-                      emit ? dst->x() : nullptr, emit ? dst->y() : nullptr, emit ? dst->z() : nullptr, emit ? dst->rgbt() : nullptr, emit);
+            CW_LAUNCH("emit_and_clean", emit_and_clean_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, vals_out, emit ? dst->x() : nullptr,
+                      emit ? dst->y() : nullptr, emit ? dst->z() : nullptr, emit ? dst->rgbt() : nullptr, emit);
             if (emit) ok = hipMemcpyAsync(c.host_words, ws.ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
             ok = c.sync() && ok;
             if (emit && ok) err |= c.host_words[C_ERR];
@@ -932,13 +1076,17 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (error_code) *error_code = (int)err;
         if (!ok) { hip_failed(hipGetLastError(), "voxel emit", __FILE__, __LINE__); return nullptr; }
 
-        if ((err & ERR_LEAVES) && !(err & ~(uint32_t)(ERR_LEAVES | ERR_LIST_FULL))) {
-            // more leaves than grids: the touched records were cleaned above; grow and run again
-            if ((size_t)leaf_cap * 4 * GRID_BYTES > ((size_t)200 << 30)) {
-                cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the cloud spans more octree leaves than fit in device memory");
-                return nullptr;
+        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LIST_FULL;
+        if ((err & (ERR_LEAVES | ERR_FACE_TABLE)) && !(err & ~retryable)) {
+            // the touched records were cleaned above; change what was too small and run again
+            if (err & ERR_FACE_TABLE) mode = 2;   // points beyond the threshold table: per-point f64 variant
+            if (err & ERR_LEAVES) {
+                if ((size_t)leaf_cap * 4 * GRID_BYTES > ((size_t)200 << 30)) {
+                    cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the cloud spans more octree leaves than fit in device memory");
+                    return nullptr;
+                }
+                leaf_cap *= 4;
             }
-            leaf_cap *= 4;
             continue;
         }
         if (err) {
@@ -947,7 +1095,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             if (err & ERR_RANGE) why += " voxel or leaf index out of range;";
             if (err & (ERR_DEPTH | ERR_LEAF_RANGE)) why += " octree deeper than 14 levels;";
             if (err & ERR_CELL_RANGE) why += " voxel outside its leaf grid;";
-            if (err & ERR_FIRST_POINT) why += " the first point is not finite;";
             if (err & ERR_LIST_FULL) why += " occupied list full;";
             if (err & 0x80000000u) why += " device allocation or sort failure;";
             cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed:" + why);

@@ -61,8 +61,10 @@ void count_dealloc() { std::lock_guard<std::mutex> l(g_alloc_mutex); g_dealloc++
 std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints) {
     auto soa = std::make_shared<DeviceSoA>();
     soa->npoints = npoints;
-    soa->stride = ((npoints + 63) / 64) * 64;
-    if (soa->stride == 0) soa->stride = 64;
+    // Planes are padded to a multiple of 256 points so that a wave's 4-points-per-lane vector
+    // loads of the last, partial step stay inside the plane without per-lane bounds checks.
+    soa->stride = ((npoints + 255) / 256) * 256;
+    if (soa->stride == 0) soa->stride = 256;
     soa->device = current_device();
     soa->base = pool_alloc(soa->stride * 16);
     if (!soa->base) return nullptr;
@@ -332,6 +334,12 @@ std::shared_ptr<DeviceSoA> cwipc_hip_pointcloud::device_points() {
             hip_failed(hipGetLastError(), "upload of point data", __FILE__, __LINE__);
             return nullptr;
         }
+    }
+    if (m_npoints) {
+        soa->first[0] = host->points[0].x;
+        soa->first[1] = host->points[0].y;
+        soa->first[2] = host->points[0].z;
+        soa->has_first = true;
     }
     m_dev = soa;
     return m_dev;
