@@ -73,12 +73,14 @@ constexpr int LTAB_PROBES = 32;
 constexpr int GRID_DIM = 68;                   // cells per axis of a leaf grid (64 + slack for fp rounding)
 constexpr int CELLS = GRID_DIM * GRID_DIM * GRID_DIM;   // 314432 < 2^19
 constexpr int CELL_BITS = 19;
+constexpr int BITWORDS = CELLS / 32;            // 9826 occupancy words per leaf grid (CELLS is a multiple of 32)
 constexpr uint32_t KEY_EMPTY = 0xffffffffu;
 constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
 constexpr int Q_BIAS = 64;                     // per-point bias of the packed offset sums (they never borrow)
 constexpr int RECORD_WORDS = 8;                // 64-byte records: sx sy sz cr gb tlo thi tor
 constexpr int FACES = 128;                     // leaf faces per axis with a precomputed threshold
-constexpr int FACE_BACK = 63;                  // the table starts 63 faces below the first point's leaf
+constexpr int FACE_BACK = 63;
+constexpr uint32_t REPLAY_LDS_RANGES = 4096;   // wave boxes the replay kernel keeps in LDS (96 KB)                  // the table starts 63 faces below the first point's leaf
 
 enum : uint32_t {
     ERR_RANGE = 1,           // voxel index outside +-2^26, or leaf index outside +-2^20
@@ -121,6 +123,9 @@ struct VoxWork {
     uint32_t *ctrl;
     float *bboxes;                   // [nranges][6]
     const float *faces;              // [3][FACES] thresholds (positive cellsize only)
+    uint32_t *bitmaps;               // [leaf hash][BITWORDS] occupancy of the leaf grids (bit = cell)
+    uint32_t *leaf_count;            // [leaf hash] occupied cells per leaf (accumulated by K1's flush)
+    uint32_t *seg_count;             // [leaf hash][RANK_SEGS] occupied cells per bitmap slice (seg_count_kernel)
 };
 
 inline __host__ __device__ uint64_t mix64(uint64_t k) {
@@ -207,6 +212,11 @@ __device__ __forceinline__ unsigned long long *record_ptr(const VoxWork &W, uint
     return W.records + ((size_t)(key >> CELL_BITS) * CELLS + (key & ((1u << CELL_BITS) - 1))) * RECORD_WORDS;
 }
 
+__device__ __forceinline__ void mark_occupied(const VoxWork &W, uint32_t key) {
+    const uint32_t cell = key & ((1u << CELL_BITS) - 1);
+    atomicOr(&W.bitmaps[(size_t)(key >> CELL_BITS) * BITWORDS + (cell >> 5)], 1u << (cell & 31u));
+}
+
 // Slow path (workgroup table saturated by incoherent input): one lane updates a whole record.
 __device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t list_cap, uint32_t key, long long sx, long long sy, long long sz,
                                                    unsigned long long cr, unsigned long long gb, uint32_t tile) {
@@ -218,6 +228,8 @@ __device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t li
     atomicAdd(&rec[4], gb);
     atomicOr(&rec[7], (unsigned long long)tile);
     if ((old >> 32) == 0) {
+        mark_occupied(W, key);
+        atomicAdd(&W.leaf_count[key >> CELL_BITS], 1u);
         const uint32_t idx = atomicAdd(&W.ctrl[C_COUNT], 1u);
         if (idx < list_cap) W.occupied[idx] = key;
         else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
@@ -247,6 +259,7 @@ struct LdsTable {
     unsigned long long d[LTAB];   // count | sum r << 16 | sum g << 40
     uint32_t fresh[LTAB];         // records this workgroup touched first
     float faces[3 * FACES];
+    uint32_t htag[64], hcnt[64];  // first touches per leaf of this workgroup (leaf id + 1, count)
     uint32_t nfresh, fresh_base;
 };
 
@@ -385,6 +398,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     if (MODE == 1) {
         for (int i = threadIdx.x; i < 3 * FACES; i += K1_THREADS) L.faces[i] = W.faces[i];
     }
+    if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
     if (threadIdx.x == 0) L.nfresh = 0;
     __syncthreads();
 
@@ -577,9 +591,18 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
         unsigned long long *rec = record_ptr(W, k);
         const unsigned long long old = atomicAdd(&rec[sub], val);
-        if (sub == 3 && (old >> 32) == 0) L.fresh[atomicAdd(&L.nfresh, 1u)] = k;
+        if (sub == 3 && (old >> 32) == 0) {
+            L.fresh[atomicAdd(&L.nfresh, 1u)] = k;
+            mark_occupied(W, k);
+            // occupied cells per leaf, aggregated per workgroup (a few leaves per workgroup)
+            const uint32_t leaf = k >> CELL_BITS, hs = leaf & 63u;
+            const uint32_t tag = atomicCAS(&L.htag[hs], 0u, leaf + 1u);
+            if (tag == 0u || tag == leaf + 1u) atomicAdd(&L.hcnt[hs], 1u);
+            else atomicAdd(&W.leaf_count[leaf], 1u);
+        }
     }
     __syncthreads();
+    if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.leaf_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
     const uint32_t nfresh = L.nfresh;
     if (threadIdx.x == 0 && nfresh) L.fresh_base = atomicAdd(&W.ctrl[C_COUNT], nfresh);
     __syncthreads();
@@ -650,6 +673,12 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         s_depth = P.depth0;
         s_events = 0;
     }
+    // the wave boxes are searched once per growth step: keep them in LDS when they fit
+    extern __shared__ float s_boxes[];
+    const bool cached = nranges <= REPLAY_LDS_RANGES;
+    if (cached) {
+        for (uint32_t i = tid; i < nranges * 6; i += 1024) s_boxes[i] = bboxes[i];
+    }
     __syncthreads();
 
     const double eps = (double)FLT_EPSILON;
@@ -661,7 +690,8 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         {
             const double mn0 = s_mn[0], mn1 = s_mn[1], mn2 = s_mn[2], mx0 = s_mx[0], mx1 = s_mx[1], mx2 = s_mx[2];
             for (uint32_t c = range + tid; c < nranges; c += 1024) {
-                const float *b = bboxes + (size_t)c * 6;
+                float b[6];
+                for (int i = 0; i < 6; i++) b[i] = cached ? s_boxes[c * 6 + i] : bboxes[(size_t)c * 6 + i];
                 const bool viol = (double)b[0] < mn0 || (double)b[1] < mn1 || (double)b[2] < mn2 ||
                                   (double)b[3] >= mx0 || (double)b[4] >= mx1 || (double)b[5] >= mx2;
                 if (viol) { atomicMin(&s_first, (unsigned long long)c); break; }
@@ -830,6 +860,165 @@ __global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWor
     }
     const ulonglong2 zero = {0ull, 0ull};
     rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
+    const uint32_t bit_cell = key & ((1u << CELL_BITS) - 1);
+    atomicAnd(&W.bitmaps[(size_t)(key >> CELL_BITS) * BITWORDS + (bit_cell >> 5)], ~(1u << (bit_cell & 31u)));
+}
+
+// ---------------------------------------------------------------------------
+// Sort-free output order for the octree path: leaves in Morton order of their final keys,
+// cells in ascending index inside a leaf = rank of a bit in the occupancy bitmaps.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool leaf_morton(const VoxWork &W, unsigned long long lp, int depth, unsigned long long &code) {
+    long long lk[3];
+    bool bad = false;
+    for (int a = 0; a < 3; a++) {
+        const long long shift = (long long)(((unsigned long long)W.ctrl[C_SHIFT + 2 * a + 1] << 32) | W.ctrl[C_SHIFT + 2 * a]);
+        lk[a] = (long long)unpack_leaf(lp, a) + shift;
+        if (lk[a] < 0 || lk[a] >= ((long long)1 << depth)) bad = true;
+    }
+    code = 0;
+    for (int b = depth - 1; b >= 0; b--) {
+        code = (code << 3) | (((unsigned long long)(lk[0] >> b) & 1) << 2) | (((unsigned long long)(lk[1] >> b) & 1) << 1) |
+               ((unsigned long long)(lk[2] >> b) & 1);
+    }
+    return !bad;
+}
+
+__device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W, unsigned long long lp, uint32_t key, uint32_t r,
+                                            float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
+    ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(record_ptr(W, key));
+    const ulonglong2 w01 = rec[0], w23 = rec[1], w45 = rec[2], w67 = rec[3];
+    const uint32_t cell = key & ((1u << CELL_BITS) - 1);
+    const int c[3] = {(int)(cell % GRID_DIM), (int)((cell / GRID_DIM) % GRID_DIM), (int)(cell / (GRID_DIM * GRID_DIM))};
+    double vox[3];
+    for (int a = 0; a < 3; a++) vox[a] = (double)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2);
+    const unsigned long long cr = w23.y, gb = w45.x;
+    const uint32_t cnt = (uint32_t)(cr >> 32);
+    // mean = voxel origin + mean offset (f64, one division), one rounding to fp32 at the end
+    const double scale = 1.0 / ((double)cnt * (double)P.fix_scale);
+    ox[r] = (float)(vox[0] * P.leaf_d + (double)(long long)w01.x * scale);
+    oy[r] = (float)(vox[1] * P.leaf_d + (double)(long long)w01.y * scale);
+    oz[r] = (float)(vox[2] * P.leaf_d + (double)(long long)w23.x * scale);
+    const float fn = (float)cnt;
+    const uint32_t rr = (uint32_t)__fdiv_rn((float)(uint32_t)(cr & 0xffffffffu), fn);
+    const uint32_t gg = (uint32_t)__fdiv_rn((float)(uint32_t)(gb >> 32), fn);
+    const uint32_t bb = (uint32_t)__fdiv_rn((float)(uint32_t)(gb & 0xffffffffu), fn);
+    uint32_t tile = (uint32_t)w67.y & 0xffu;
+    for (int b = 0; b < 4; b++) {
+        if ((w45.y >> (16 * b)) & 0xffffull) tile |= 1u << b;
+        if ((w67.x >> (16 * b)) & 0xffffull) tile |= 16u << b;
+    }
+    ow[r] = (rr & 0xffu) | ((gg & 0xffu) << 8) | ((bb & 0xffu) << 16) | (tile << 24);
+    const ulonglong2 zero = {0ull, 0ull};
+    rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
+}
+
+// RANK_SEGS workgroups per leaf, each owning a contiguous slice of the leaf's bitmap: output base
+// of the leaf (cells of all leaves that precede it in Morton order) + occupied cells in the
+// earlier slices, ranks of the slice's cells from a popcount scan, then gather, emit and clean.
+// Replaces the key sort: no pass over the outputs other than the emit itself.
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_SEGS = 8;
+constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 1229
+constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 5
+
+__global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, VoxWork W, uint32_t leaf_cap, uint32_t m, uint32_t *order,
+                                                                 float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
+                                                                 uint32_t *__restrict__ ow) {
+    __shared__ uint32_t wave_tot[RANK_THREADS / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t p = blockIdx.x / RANK_SEGS, seg = blockIdx.x % RANK_SEGS;
+    const unsigned long long lp = W.leaf_keys[p];
+    if (lp == 0ull) return;
+    const int depth = (int)W.ctrl[C_DEPTH];
+    unsigned long long mine;
+    if (depth > 14 || !leaf_morton(W, lp, depth, mine)) {
+        if (threadIdx.x == 0) atomicOr(&W.ctrl[C_ERR], depth > 14 ? ERR_DEPTH : ERR_LEAF_RANGE);
+        return;   // the host cleans up through the occupied list
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *bm = W.bitmaps + (size_t)p * BITWORDS;
+    const int w_lo = (int)seg * SEG_WORDS;
+    const int w_hi = min(w_lo + SEG_WORDS, BITWORDS);
+    // ---- base: cells of the leaves that come first, plus this leaf's cells in earlier slices ----
+    uint32_t before = 0;
+    for (uint32_t q = threadIdx.x; q < leaf_cap; q += RANK_THREADS) {
+        const unsigned long long lq = W.leaf_keys[q];
+        unsigned long long other;
+        if (lq != 0ull && q != p && leaf_morton(W, lq, depth, other) && other < mine) before += W.leaf_count[q];
+    }
+    // earlier slices may already have been cleaned by their own workgroups, so their cells are
+    // counted from the snapshot seg_count_kernel took before any cleaning started
+    for (uint32_t sg = threadIdx.x; sg < seg; sg += RANK_THREADS) before += W.seg_count[p * RANK_SEGS + sg];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+    if (lane == 0) wave_tot[wave] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < RANK_THREADS / 64; w++) t += wave_tot[w];
+        s_base = t;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    __syncthreads();
+    // ---- ranks inside the slice: each lane owns WORDS_PER_THREAD consecutive bitmap words ----
+    uint32_t words[WORDS_PER_THREAD];
+    uint32_t mycount = 0;
+#pragma unroll
+    for (int i = 0; i < WORDS_PER_THREAD; i++) {
+        const int w = w_lo + threadIdx.x * WORDS_PER_THREAD + i;
+        words[i] = w < w_hi ? bm[w] : 0u;
+        mycount += __popc(words[i]);
+    }
+    uint32_t inc = mycount;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int w = 0; w < RANK_THREADS / 64; w++) {
+        if (w < wave) wbase += wave_tot[w];
+        total += wave_tot[w];
+    }
+    uint32_t rank = base + wbase + inc - mycount;
+    // phase 1: write the slice's cells in rank order (stores only: no dependent loads in this serial part)
+#pragma unroll
+    for (int i = 0; i < WORDS_PER_THREAD; i++) {
+        uint32_t bits = words[i];
+        const int w = w_lo + threadIdx.x * WORDS_PER_THREAD + i;
+        if (bits) bm[w] = 0u;   // clean
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            if (rank < m) order[rank] = (p << CELL_BITS) | (uint32_t)(w * 32 + b);
+            else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+            rank++;
+        }
+    }
+    __syncthreads();   // this workgroup's order[] stores are visible to its own lanes from here on
+    // phase 2: gather, emit and clean, one cell per lane
+    for (uint32_t i = threadIdx.x; i < total; i += RANK_THREADS) {
+        const uint32_t r = base + i;
+        if (r < m) emit_record(P, W, lp, __hip_atomic_load(&order[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r, ox, oy, oz, ow);
+    }
+}
+
+// Occupied cells per bitmap slice, taken before rank_emit starts cleaning.
+__global__ void __launch_bounds__(256) seg_count_kernel(VoxWork W) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t p = blockIdx.x / RANK_SEGS, seg = blockIdx.x % RANK_SEGS;
+    uint32_t c = 0;
+    if (W.leaf_keys[p] != 0ull) {
+        const uint32_t *bm = W.bitmaps + (size_t)p * BITWORDS;
+        const int w_lo = (int)seg * SEG_WORDS, w_hi = min(w_lo + SEG_WORDS, BITWORDS);
+        for (int w = w_lo + threadIdx.x; w < w_hi; w += 256) c += __popc(bm[w]);
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) W.seg_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // ---------------------------------------------------------------------------
@@ -845,6 +1034,8 @@ struct Workspace {
     uint32_t *occupied = nullptr;
     float *bboxes = nullptr;
     uint32_t *ctrl = nullptr;
+    uint32_t *bitmaps = nullptr;
+    uint32_t *leaf_count = nullptr;
     float *faces = nullptr;            // device copy of the threshold table
     float faces_host[3 * FACES];       // what the device copy holds
     bool faces_valid = false;
@@ -856,6 +1047,9 @@ struct Workspace {
         if (bboxes) (void)hipFree(bboxes);
         if (ctrl) (void)hipFree(ctrl);
         if (faces) (void)hipFree(faces);
+        if (bitmaps) (void)hipFree(bitmaps);
+        if (leaf_count) (void)hipFree(leaf_count);
+        bitmaps = nullptr; leaf_count = nullptr;
         leaf_keys = nullptr; records = nullptr; occupied = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
         leaf_cap = 0; list_cap = 0; bbox_cap = 0;
         faces_valid = false;
@@ -875,13 +1069,20 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&octree_replay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(REPLAY_LDS_RANGES * 6 * sizeof(float))));
         ws.device = dev;
     }
     if (ws.leaf_cap < leaf_cap) {
         if (ws.leaf_keys) (void)hipFree(ws.leaf_keys);
         if (ws.records) (void)hipFree(ws.records);
-        ws.leaf_keys = nullptr; ws.records = nullptr; ws.leaf_cap = 0;
+        if (ws.bitmaps) (void)hipFree(ws.bitmaps);
+        if (ws.leaf_count) (void)hipFree(ws.leaf_count);
+        ws.leaf_keys = nullptr; ws.records = nullptr; ws.bitmaps = nullptr; ws.leaf_count = nullptr; ws.leaf_cap = 0;
         CW_HIP_TRY(hipMalloc((void **)&ws.leaf_keys, (size_t)leaf_cap * 8));
+        CW_HIP_TRY(hipMalloc((void **)&ws.bitmaps, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t)));
+        CW_HIP_TRY(hipMemsetAsync(ws.bitmaps, 0, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t), s));
+        CW_HIP_TRY(hipMalloc((void **)&ws.leaf_count, (size_t)leaf_cap * (1 + RANK_SEGS) * sizeof(uint32_t)));   // leaf counts, then slice counts
         CW_HIP_TRY(hipMalloc((void **)&ws.records, (size_t)leaf_cap * GRID_BYTES));
         CW_HIP_TRY(hipMemsetAsync(ws.records, 0, (size_t)leaf_cap * GRID_BYTES, s));   // once; K4 keeps it clean afterwards
         ws.leaf_cap = leaf_cap;
@@ -982,10 +1183,11 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
-        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces};
+        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.leaf_count, ws.leaf_count + ws.leaf_cap};
 
         bool ok = hipMemsetAsync(ws.ctrl, 0, C_WORDS * sizeof(uint32_t), c.stream) == hipSuccess &&
-                  hipMemsetAsync(ws.leaf_keys, 0, (size_t)ws.leaf_cap * 8, c.stream) == hipSuccess;
+                  hipMemsetAsync(ws.leaf_keys, 0, (size_t)ws.leaf_cap * 8, c.stream) == hipSuccess &&
+                  hipMemsetAsync(ws.leaf_count, 0, (size_t)ws.leaf_cap * sizeof(uint32_t), c.stream) == hipSuccess;
         if (ok && mode == 1 && !(ws.faces_valid && memcmp(ws.faces_host, faces_host, sizeof(faces_host)) == 0)) {
             float *stage = (float *)c.staging(sizeof(faces_host));
             ok = stage != nullptr;
@@ -1017,7 +1219,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(),
                       src.y(), src.z(), src.rgbt(), W);
         }
-        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl);
+        const size_t replay_lds = (leaf_split && nwaves <= REPLAY_LDS_RANGES) ? nwaves * 6 * sizeof(float) : 0;
+        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), replay_lds, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl);
         ok = hipMemcpyAsync(c.host_words, ws.ctrl, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
         ok = c.sync() && ok;
         if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
@@ -1031,7 +1234,26 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         void *sort_tmp = nullptr;
         const unsigned mgrid = (m + 255) / 256;
 
-        if (!err && m) {
+        bool ranked = false;
+        if (!err && m && leaf_split) {
+            // octree path: rank the occupied cells through the bitmaps, emit, clean -- no sort
+            dst = soa_alloc(m);
+            uint32_t *order_buf = (uint32_t *)pool_alloc((size_t)m * sizeof(uint32_t));
+            if (!dst || !order_buf) {
+                err |= 0x80000000u;
+                pool_free(order_buf);
+            } else {
+                CW_LAUNCH("seg_count", seg_count_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(256), 0, c.stream, W);
+                CW_LAUNCH("rank_emit", rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, m, order_buf,
+                          dst->x(), dst->y(), dst->z(), dst->rgbt());
+                ok = hipMemcpyAsync(c.host_words, ws.ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+                ok = c.sync() && ok;
+                if (ok) err |= c.host_words[C_ERR];
+                ranked = ok && !err;
+                pool_free(order_buf);
+            }
+        }
+        if (!err && m && !leaf_split) {
             dst = soa_alloc(m);
             keys_in = (unsigned long long *)pool_alloc((size_t)m * 8 * 2);
             vals_in = (uint32_t *)pool_alloc((size_t)m * 4 * 2);
@@ -1061,9 +1283,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 }
             }
         }
-        if (m) {
+        if (m && !ranked) {
             // emit (or, on error, only clean): the records must be left zeroed either way
-            const int emit = (!err && dst) ? 1 : 0;
+            const int emit = (!err && dst && !leaf_split) ? 1 : 0;
             CW_LAUNCH("emit_and_clean", emit_and_clean_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, vals_out, emit ? dst->x() : nullptr,
                       emit ? dst->y() : nullptr, emit ? dst->z() : nullptr, emit ? dst->rgbt() : nullptr, emit);
             if (emit) ok = hipMemcpyAsync(c.host_words, ws.ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
