@@ -76,7 +76,14 @@ constexpr int CELL_BITS = 19;
 constexpr int BITWORDS = CELLS / 32;            // 9826 occupancy words per leaf grid (CELLS is a multiple of 32)
 constexpr uint32_t KEY_EMPTY = 0xffffffffu;
 constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
-constexpr int Q_BIAS = 64;                     // per-point bias of the packed offset sums (they never borrow)
+// Offsets are summed with a per-point bias so that the packed sums never borrow.  fl(f * inv_leaf)
+// may land |g| * 2^-23 voxels away from f / leaf, so an offset lies in [-|g| / 2, 2^22 + |g| / 2] units:
+// the normal scale (2^22 units per voxel, bias 2^21) holds for clouds within 4e6 voxels of the origin;
+// beyond that the host reruns with the wide scale (2^14 units, bias 2^19: +-32 voxels, and still far
+// finer than the spacing of fp32 coordinates out there).
+constexpr float FIX_ONE_WIDE_F = 16384.0f;
+constexpr uint32_t Q_BIAS = 1u << 21, Q_BIAS_WIDE = 1u << 19;
+constexpr float G_CHECK = 4.0e6f;
 constexpr int RECORD_WORDS = 8;                // 64-byte records: sx sy sz cr gb tlo thi tor
 constexpr int FACES = 128;                     // leaf faces per axis with a precomputed threshold
 constexpr int FACE_BACK = 63;
@@ -91,6 +98,7 @@ enum : uint32_t {
     ERR_FACE_TABLE = 32,     // a point lies beyond the threshold table (host reruns the exact variant)
     ERR_CELL_RANGE = 64,
     ERR_LIST_FULL = 128,
+    ERR_FIXED_RANGE = 256,   // coordinates beyond 4e6 voxels: host reruns with the wide fixed-point scale
 };
 
 // control block, 32-bit words in device memory
@@ -239,6 +247,11 @@ __device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t li
 // ---------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------
+// K1 is bound by instruction issue, not by HBM (rocprofv3: ~230 VALU instructions per point in the
+// first version, VALU busy 60 %, waves parked 58 % with 4 waves per SIMD), so the hot loop below is
+// written for instruction count: wave-uniform values in SGPRs, selects instead of branches, 32-bit
+// arithmetic, byte permutes for the colour sums, and slow paths behind wave-uniform ballots.
+
 // One run of points of the same voxel, 32-bit in-wave form (at most 256 points).
 struct Run32 {
     uint32_t key;       // leaf id << 19 | cell, KEY_EMPTY = none
@@ -270,18 +283,24 @@ struct K1Params {
     int ib0, ib1, ib2;
     int fb0, fb1, fb2;
     uint32_t leaf_mask, list_cap, ablate;
+    uint32_t q_bias;    // per-point bias of the offset sums
+    float g_check;      // |coordinate * inv_leaf| a wave may see at this scale (inf: no limit)
     double mn0[3];      // MODE 2 only
     double res;
 };
 
-__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32_t list_cap, const Run32 &r) {
+__device__ __forceinline__ unsigned long long u64_of(uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; }
+
+// Add one run to the workgroup table.  All in-wave sums are 32-bit (<= 256 points), so the four
+// packed 64-bit addends are assembled from 32-bit halves.
+__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32_t list_cap, uint32_t q_bias, const Run32 &r) {
     uint32_t slot = (r.key * 0x9E3779B1u) >> (32 - 11);   // LTAB = 2^11
-    const unsigned long long cnt = r.cr >> 16, rs = r.cr & 0xffffu, gs = r.gb >> 16, bs = r.gb & 0xffffu;
-    const unsigned long long bias = cnt * Q_BIAS;
-    const unsigned long long A = (unsigned long long)((long long)r.qx + (long long)bias);
-    const unsigned long long B = (unsigned long long)((long long)r.qy + (long long)bias);
-    const unsigned long long C = (unsigned long long)((long long)r.qz + (long long)bias) | (bs << 40);
-    const unsigned long long D = cnt | (rs << 16) | (gs << 40);
+    const uint32_t cnt = r.cr >> 16, bias = cnt * q_bias;   // every q + q_bias is >= 0, so the sums fit unsigned 32 bits
+    const unsigned long long A = u64_of((uint32_t)(r.qx + (int)bias), 0u);
+    const unsigned long long B = u64_of((uint32_t)(r.qy + (int)bias), 0u);
+    const unsigned long long C = u64_of((uint32_t)(r.qz + (int)bias), (r.gb & 0xffffu) << 8);                     // | sum b << 40
+    const unsigned long long D = u64_of(__builtin_amdgcn_alignbit(r.cr, r.cr, 16), (r.gb >> 16) << 8);           // count | sum r << 16 | sum g << 40
+    bool done = false;
     for (int probe = 0; probe < LTAB_PROBES; probe++) {
         const uint32_t old = atomicCAS(&L.key[slot], KEY_EMPTY, r.key);
         if (old == KEY_EMPTY || old == r.key) {
@@ -290,11 +309,14 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32
             atomicAdd(&L.c[slot], C);
             atomicAdd(&L.d[slot], D);
             atomicOr(&L.tile[slot], r.tile);
-            return;
+            done = true;
+            break;
         }
         slot = (slot + 1) & (LTAB - 1);
     }
-    global_insert_lane(W, list_cap, r.key, r.qx, r.qy, r.qz, (cnt << 32) | rs, (gs << 32) | bs, r.tile);
+    if (!done) {
+        global_insert_lane(W, list_cap, r.key, r.qx, r.qy, r.qz, u64_of(r.cr & 0xffffu, cnt), u64_of(r.gb & 0xffffu, r.gb >> 16), r.tile);
+    }
 }
 
 // DPP row shifts inside rows of 16 lanes (lanes whose source is outside the row read 0).
@@ -320,68 +342,72 @@ __device__ __forceinline__ void scan_step(Run32 &v, int &flag) {
     flag |= dpp_shr<N>(flag);
 }
 
+// Two consecutive leaf faces of one axis, wave-uniform: faces mc and mc + 1 with their thresholds.
+struct FaceCache {
+    int mc;
+    float tlo, thi;
+};
+
 struct PointOut {
     uint32_t key;   // cell inside the leaf grid, KEY_EMPTY if the point is skipped
     int l0, l1, l2; // leaf lattice coordinates
     int q0, q1, q2; // fixed-point offsets
+    bool seen;      // the point exists and is finite (whatever the face caches say)
 };
 
-// MODE 0: plain grid (bricks on the voxel lattice); 1: octree leaves by threshold table; 2: octree leaves by f64 division.
-// Branch-free: `good` collects validity, `err` the error bits of this lane.
+// MODE 0: plain grid (bricks on the voxel lattice); 1: octree leaves by face thresholds; 2: octree leaves by f64 division.
 template <int MODE>
-__device__ __forceinline__ void axis_cell(const K1Params &P, const float *faces, int ib, int fb, int axis, float f, bool &good, bool &huge,
-                                          bool &off_table, int &l, int &c, int &q) {
+__device__ __forceinline__ void axis_cell(const K1Params &P, int ib, const FaceCache &fc, int axis, float f, bool &good, bool &miss, int &t_out,
+                                          int &l, int &c, int &q) {
     float g = floorf(__fmul_rn(f, P.inv_leaf));   // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
-    const bool in = fabsf(g) < 33554432.0f;       // false for NaN / Inf / absurdly far points
-    good &= in;
-    huge |= !in && fabsf(f) < INFINITY;           // finite but out of range: an error, not a skipped point
-    g = fminf(fmaxf(g, -33554432.0f), 33554432.0f);
+    good &= fabsf(g) < 33554432.0f;               // false for NaN / Inf / points beyond 2^25 voxels
+    g = __builtin_amdgcn_fmed3f(g, -33554432.0f, 33554432.0f);
     const int t = (int)g - ib;
+    t_out = t;
     if (MODE == 0) {
         l = t >> 6;
     } else if (MODE == 1) {
-        const int m = (t + 32) >> 6;                    // the leaf face nearest to this voxel
-        const unsigned i = (unsigned)(m - fb);
-        const bool oob = i >= (unsigned)FACES;
-        off_table |= oob;
-        const float T = faces[axis * FACES + (oob ? 0u : i)];
-        l = m - (f < T ? 1 : 0);
+        // leaf = (face mc - 1) + [f >= T(mc)] + [f >= T(mc + 1)], valid while the voxel lies between faces mc - 1/2 and mc + 3/2
+        miss |= (unsigned)(t - (fc.mc * 64 - 32)) >= 128u;
+        l = fc.mc - 1 + (f >= fc.tlo ? 1 : 0) + (f >= fc.thi ? 1 : 0);
     } else {
         l = (int)floor(((double)f - P.mn0[axis]) / P.res);   // genOctreeKeyforPoint
     }
     c = t - 64 * l + 2;
-    good &= (unsigned)c < (unsigned)GRID_DIM;
     // offset inside the voxel in 2^-22 voxel units; one rounding each (fma, product, convert)
     q = (int)rintf(__fmul_rn(fmaf(-g, P.leaf, f), P.fix_scale));
 }
 
 template <int MODE>
-__device__ __forceinline__ PointOut point_key(const K1Params &P, const float *faces, float fx, float fy, float fz, bool present, uint32_t &err,
-                                              float &bn0, float &bn1, float &bn2, float &bx0, float &bx1, float &bx2) {
+__device__ __forceinline__ PointOut point_key(const K1Params &P, const FaceCache &f0, const FaceCache &f1, const FaceCache &f2, float fx, float fy,
+                                              float fz, bool present, bool &miss, int &t0, int &t1, int &t2, float &bn0, float &bn1, float &bn2,
+                                              float &bx0, float &bx1, float &bx2) {
     PointOut o;
-    bool good = present, huge = false, off_table = false;
+    bool good = present, pmiss = false;
     int c0, c1, c2;
-    axis_cell<MODE>(P, faces, P.ib0, P.fb0, 0, fx, good, huge, off_table, o.l0, c0, o.q0);
-    axis_cell<MODE>(P, faces, P.ib1, P.fb1, 1, fy, good, huge, off_table, o.l1, c1, o.q1);
-    axis_cell<MODE>(P, faces, P.ib2, P.fb2, 2, fz, good, huge, off_table, o.l2, c2, o.q2);
-    // the octree skips non-finite points (addPointsFromInputCloud: isFinite); they do not enter the boxes either
-    const bool finite = present && fabsf(fx) < INFINITY && fabsf(fy) < INFINITY && fabsf(fz) < INFINITY;
-    bn0 = fminf(bn0, finite ? fx : FLT_MAX); bx0 = fmaxf(bx0, finite ? fx : -FLT_MAX);
-    bn1 = fminf(bn1, finite ? fy : FLT_MAX); bx1 = fmaxf(bx1, finite ? fy : -FLT_MAX);
-    bn2 = fminf(bn2, finite ? fz : FLT_MAX); bx2 = fmaxf(bx2, finite ? fz : -FLT_MAX);
-    if (MODE == 1) {
-        err |= (finite && off_table && !huge) ? ERR_FACE_TABLE : 0u;
-        good &= !off_table;
-    }
-    err |= (finite && (huge || (!good && !off_table))) ? ERR_RANGE : 0u;
-    o.key = (good && finite) ? (uint32_t)((c2 * GRID_DIM + c1) * GRID_DIM + c0) : KEY_EMPTY;
+    axis_cell<MODE>(P, P.ib0, f0, 0, fx, good, pmiss, t0, o.l0, c0, o.q0);
+    axis_cell<MODE>(P, P.ib1, f1, 1, fy, good, pmiss, t1, o.l1, c1, o.q1);
+    axis_cell<MODE>(P, P.ib2, f2, 2, fz, good, pmiss, t2, o.l2, c2, o.q2);
+    // Non-finite points are skipped as the octree does (addPointsFromInputCloud: isFinite) and stay out of
+    // the boxes: NaN is the neutral element of v_min/v_max.  So are points beyond 2^25 voxels.
+    const float nan = __uint_as_float(0x7fc00000u);
+    const float sx = good ? fx : nan, sy = good ? fy : nan, sz = good ? fz : nan;
+    bn0 = fminf(bn0, sx); bx0 = fmaxf(bx0, sx);
+    bn1 = fminf(bn1, sy); bx1 = fmaxf(bx1, sy);
+    bn2 = fminf(bn2, sz); bx2 = fmaxf(bx2, sz);
+    miss |= pmiss && good;
+    o.seen = good;
+    // memory safety: a cell outside the leaf grid must never become a record address
+    good &= (unsigned)c0 < (unsigned)GRID_DIM && (unsigned)c1 < (unsigned)GRID_DIM && (unsigned)c2 < (unsigned)GRID_DIM;
+    o.key = good ? (uint32_t)((c2 * GRID_DIM + c1) * GRID_DIM + c0) : KEY_EMPTY;
     return o;
 }
 
+// r,g,b,tile bytes of one point into the run sums: two byte permutes instead of shifts and masks
 __device__ __forceinline__ void add_point(Run32 &r, const PointOut &o, uint32_t w) {
     r.qx += o.q0; r.qy += o.q1; r.qz += o.q2;
-    r.cr += (1u << 16) | (w & 0xffu);
-    r.gb += (((w >> 8) & 0xffu) << 16) | ((w >> 16) & 0xffu);
+    r.cr += (w & 0xffu) | 0x10000u;                                   // count << 16 | r
+    r.gb += __builtin_amdgcn_perm(0u, w, 0x0c010c02u);                // bytes [b, 0, g, 0] = g << 16 | b
     r.tile |= w >> 24;
 }
 
@@ -403,7 +429,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const uint32_t range = blockIdx.x * K1_WAVES + (threadIdx.x >> 6);
+    // everything that is the same for the whole wave lives in SGPRs
+    const uint32_t range = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * K1_WAVES + (threadIdx.x >> 6)));
     float bn0 = FLT_MAX, bn1 = FLT_MAX, bn2 = FLT_MAX, bx0 = -FLT_MAX, bx1 = -FLT_MAX, bx2 = -FLT_MAX;
     uint32_t err = 0;
     // this wave's range [lo, hi); planes are padded to a multiple of 256 points, so whole steps can be loaded
@@ -415,7 +442,10 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     const float4 *vz = reinterpret_cast<const float4 *>(z + lo) + lane;
     const uint4 *vw = reinterpret_cast<const uint4 *>(rgbt + lo) + lane;
 
-    // wave-uniform cache of the last leaf and its id
+    // wave-uniform caches: two leaf faces per axis, the last leaf and its id
+    FaceCache fc0, fc1, fc2;
+    fc0.mc = fc1.mc = fc2.mc = -(1 << 24);   // covers nothing yet
+    fc0.tlo = fc0.thi = fc1.tlo = fc1.thi = fc2.tlo = fc2.thi = 0.f;
     int cl0 = 0, cl1 = 0, cl2 = 0;
     uint32_t cache_id = 0xffffffffu;
     bool cache_valid = false;
@@ -442,10 +472,50 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
 
         // ---- per point: cell, leaf lattice coordinates, fixed-point offsets (branch-free) ----
-        PointOut o0 = point_key<MODE>(P, L.faces, cx.x, cy.x, cz.x, left > 0, err, bn0, bn1, bn2, bx0, bx1, bx2);
-        PointOut o1 = point_key<MODE>(P, L.faces, cx.y, cy.y, cz.y, left > 1, err, bn0, bn1, bn2, bx0, bx1, bx2);
-        PointOut o2 = point_key<MODE>(P, L.faces, cx.z, cy.z, cz.z, left > 2, err, bn0, bn1, bn2, bx0, bx1, bx2);
-        PointOut o3 = point_key<MODE>(P, L.faces, cx.w, cy.w, cz.w, left > 3, err, bn0, bn1, bn2, bx0, bx1, bx2);
+        bool miss = false;
+        int t00, t01, t02, t10, t11, t12, t20, t21, t22, t30, t31, t32;
+        PointOut o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0, miss, t00, t01, t02, bn0, bn1, bn2, bx0, bx1, bx2);
+        PointOut o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1, miss, t10, t11, t12, bn0, bn1, bn2, bx0, bx1, bx2);
+        PointOut o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2, miss, t20, t21, t22, bn0, bn1, bn2, bx0, bx1, bx2);
+        PointOut o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3, miss, t30, t31, t32, bn0, bn1, bn2, bx0, bx1, bx2);
+
+        if (MODE == 1 && __ballot(miss) != 0ull) {
+            // Some voxel of this step is not between the cached faces: move each axis' cache to the lowest
+            // face this step needs (thresholds come from the table the host computed), redo the step, and if
+            // lanes are still not covered (incoherent input) give up: the host reruns the exact variant.
+            const int big = 1 << 30;
+            int w0 = big, w1 = big, w2 = big;
+            if (o0.seen) { w0 = min(w0, t00); w1 = min(w1, t01); w2 = min(w2, t02); }
+            if (o1.seen) { w0 = min(w0, t10); w1 = min(w1, t11); w2 = min(w2, t12); }
+            if (o2.seen) { w0 = min(w0, t20); w1 = min(w1, t21); w2 = min(w2, t22); }
+            if (o3.seen) { w0 = min(w0, t30); w1 = min(w1, t31); w2 = min(w2, t32); }
+            for (int s = 32; s > 0; s >>= 1) {
+                w0 = min(w0, __shfl_xor(w0, s, 64)); w1 = min(w1, __shfl_xor(w1, s, 64)); w2 = min(w2, __shfl_xor(w2, s, 64));
+            }
+            bool off_table = false;
+            auto refill = [&](FaceCache &fc, int tmin, int fb, int axis) {
+                if (tmin == big) return;
+                const int m = (tmin + 32) >> 6;                 // nearest face of the lowest voxel
+                const unsigned i = (unsigned)(m - fb);
+                if (i + 1u >= (unsigned)FACES) { off_table = true; return; }
+                fc.mc = m;
+                fc.tlo = L.faces[axis * FACES + i];
+                fc.thi = L.faces[axis * FACES + i + 1];
+            };
+            refill(fc0, __builtin_amdgcn_readfirstlane(w0), P.fb0, 0);
+            refill(fc1, __builtin_amdgcn_readfirstlane(w1), P.fb1, 1);
+            refill(fc2, __builtin_amdgcn_readfirstlane(w2), P.fb2, 2);
+            miss = false;
+            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;   // the boxes already hold this step
+            o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0, miss, t00, t01, t02, d0, d1, d2, d3, d4, d5);
+            o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1, miss, t10, t11, t12, d0, d1, d2, d3, d4, d5);
+            o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2, miss, t20, t21, t22, d0, d1, d2, d3, d4, d5);
+            o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3, miss, t30, t31, t32, d0, d1, d2, d3, d4, d5);
+            if (off_table || __ballot(miss) != 0ull) {
+                err |= ERR_FACE_TABLE;
+                o0.key = o1.key = o2.key = o3.key = KEY_EMPTY;
+            }
+        }
 
         if (P.ablate & 2u) {   // diagnostics: loads + per-point arithmetic only
             bx0 = fmaxf(bx0, __uint_as_float((o0.key ^ o1.key ^ o2.key ^ o3.key) + (uint32_t)(o0.q0 + o1.q1 + o2.q2 + o3.q0 + o0.l0 + o1.l1 + o2.l2)));
@@ -521,23 +591,21 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 
         // ---- insert rounds: round k carries run k of every lane (round 0: chain ends of merged lanes) ----
         if (!(P.ablate & 4u)) {
+            if (chain_end) lds_insert(L, W, P.list_cap, P.q_bias, v);
+            if (__ballot(!single && nruns > 1) != 0ull) {
 #pragma unroll 1
-            for (int k = 0; k < 4; k++) {
-                if (k > 0 && __ballot(!single && nruns > k) == 0ull) break;
-                Run32 r;
-                r.key = KEY_EMPTY;
-                r.qx = r.qy = r.qz = 0;
-                r.cr = r.gb = r.tile = 0;
-                if (k == 0) { r.key = o0.key; add_point(r, o0, cw.x); }
-                if (k == ri1) { r.key = o1.key; add_point(r, o1, cw.y); }
-                if (k == ri2) { r.key = o2.key; add_point(r, o2, cw.z); }
-                if (k == ri3) { r.key = o3.key; add_point(r, o3, cw.w); }
-                bool act = k < nruns && r.key != KEY_EMPTY;
-                if (single) {
-                    r = v;
-                    act = chain_end && k == 0;
+                for (int k = 0; k < 4; k++) {
+                    if (__ballot(!single && nruns > k) == 0ull) break;
+                    Run32 r;
+                    r.key = KEY_EMPTY;
+                    r.qx = r.qy = r.qz = 0;
+                    r.cr = r.gb = r.tile = 0;
+                    if (k == 0) { r.key = o0.key; add_point(r, o0, cw.x); }
+                    if (k == ri1) { r.key = o1.key; add_point(r, o1, cw.y); }
+                    if (k == ri2) { r.key = o2.key; add_point(r, o2, cw.z); }
+                    if (k == ri3) { r.key = o3.key; add_point(r, o3, cw.w); }
+                    if (!single && k < nruns && r.key != KEY_EMPTY) lds_insert(L, W, P.list_cap, P.q_bias, r);
                 }
-                if (act) lds_insert(L, W, P.list_cap, r);
             }
         }
         cx = nx; cy = ny; cz = nz; cw = nw;
@@ -558,6 +626,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             if (lane == 0) {
                 W.bboxes[(size_t)range * 6 + a] = vlo;
                 W.bboxes[(size_t)range * 6 + 3 + a] = vhi;
+                // too far out for this fixed-point scale (the pass is discarded, its records cleaned)
+                if (vlo <= vhi && fmaxf(fabsf(vlo), fabsf(vhi)) * P.inv_leaf >= P.g_check) atomicOr(&W.ctrl[C_ERR], ERR_FIXED_RANGE);
             }
         }
     }
@@ -571,7 +641,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         if (k == KEY_EMPTY || (P.ablate & 8u)) continue;
         const uint32_t t = L.tile[e];
         const unsigned long long ea = L.a[e], eb = L.b[e], ec = L.c[e], ed = L.d[e];
-        const unsigned long long cnt = ed & 0xffffull, bias = cnt * Q_BIAS;
+        const unsigned long long cnt = ed & 0xffffull, bias = cnt * P.q_bias;
         unsigned long long val;
         switch (sub) {
         case 0: val = ea - bias; break;                                      // sum qx (two's complement)
@@ -1149,6 +1219,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     P.leaf = cellsize;
     P.inv_leaf = 1.0f / cellsize;
     P.fix_scale = FIX_ONE_F / cellsize;
+    bool wide = false;
     P.leaf_d = (double)cellsize;
     const float octree_cellsize = (8 * 8) * cellsize;   // reference src/cwipc_filters.cpp:113-114
     P.res = (double)octree_cellsize;
@@ -1179,7 +1250,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
 
     uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 64;   // 64 grids = 1.3 GB; grown x4 when a cloud has more leaves
     int mode = leaf_split ? 1 : 0;
-    for (int attempt = 0; attempt < 6; attempt++) {
+    for (int attempt = 0; attempt < 9; attempt++) {
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
@@ -1207,6 +1278,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         K.ib0 = P.ib[0]; K.ib1 = P.ib[1]; K.ib2 = P.ib[2];
         K.fb0 = P.face_base[0]; K.fb1 = P.face_base[1]; K.fb2 = P.face_base[2];
         K.leaf_mask = P.leaf_mask; K.list_cap = P.list_cap; K.ablate = P.ablate;
+        K.q_bias = wide ? Q_BIAS_WIDE : Q_BIAS;
+        K.g_check = wide ? INFINITY : G_CHECK;
         K.mn0[0] = P.mn0[0]; K.mn0[1] = P.mn0[1]; K.mn0[2] = P.mn0[2];
         K.res = P.res;
         if (mode == 0) {
@@ -1298,10 +1371,14 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (error_code) *error_code = (int)err;
         if (!ok) { hip_failed(hipGetLastError(), "voxel emit", __FILE__, __LINE__); return nullptr; }
 
-        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LIST_FULL;
-        if ((err & (ERR_LEAVES | ERR_FACE_TABLE)) && !(err & ~retryable)) {
+        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE | ERR_LIST_FULL;
+        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE)) && !(err & ~retryable)) {
             // the touched records were cleaned above; change what was too small and run again
             if (err & ERR_FACE_TABLE) mode = 2;   // points beyond the threshold table: per-point f64 variant
+            if (err & ERR_FIXED_RANGE) {
+                wide = true;
+                P.fix_scale = FIX_ONE_WIDE_F / cellsize;
+            }
             if (err & ERR_LEAVES) {
                 if ((size_t)leaf_cap * 4 * GRID_BYTES > ((size_t)200 << 30)) {
                     cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the cloud spans more octree leaves than fit in device memory");

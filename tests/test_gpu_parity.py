@@ -280,6 +280,43 @@ def test_downsample_shifted_and_rotated(gpu, oracle, synth):
         check_downsample(gpu, oracle, p[rng.permutation(len(p))], cs, 0.02)
 
 
+def test_downsample_points_on_voxel_faces(gpu, oracle):
+    """Coordinates that are exact multiples of the cell size: fl(x * inv_leaf) puts them a hair
+    below their voxel's origin, i.e. the offset inside the voxel is slightly negative."""
+    rng = np.random.default_rng(21)
+    n = 60000
+    pts = oracle.empty(n)
+    for f, base in (('x', -25.0), ('y', 3.0), ('z', 0.0)):
+        pts[f] = (base + rng.integers(-40, 40, n) * 0.01).astype(np.float32)
+    pts['r'], pts['g'], pts['b'] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n)
+    pts['tile'] = 1 << rng.integers(0, 4, n)
+    for cell in (0.01, -0.01, 0.02):
+        check_downsample(gpu, oracle, pts, 0.0, cell)
+
+
+def test_downsample_far_from_origin(gpu, oracle):
+    """More than 4e6 voxels from the origin the fixed-point scale of the accumulators is widened (second pass)."""
+    rng = np.random.default_rng(22)
+    n = 50000
+    pts = oracle.empty(n)
+    pts['x'] = (50000.0 + rng.random(n) * 0.5).astype(np.float32)
+    pts['y'] = (-70000.0 + rng.random(n) * 0.5).astype(np.float32)
+    pts['z'] = (rng.random(n) * 0.5).astype(np.float32)
+    pts['r'], pts['g'], pts['b'] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n)
+    pts['tile'] = 1 << rng.integers(0, 4, n)
+    for cell in (0.01, -0.01):
+        pc = make_cloud(gpu, pts, 0.0, 1)
+        got = gpu.cwipc_downsample(pc, cell).get_numpy_array()
+        exp, _ = oracle.downsample(pts, 0.0, cell)
+        assert len(got) == len(exp)
+        for f in ('x', 'y', 'z'):
+            # the oracle's fp32 running sums are good to a few ulp out here (ulp = 0.004 at 5e4)
+            ulp = np.spacing(np.abs(exp[f]).astype(np.float32)).astype(np.float64)
+            assert (np.abs(got[f].astype(np.float64) - exp[f]) <= np.maximum(4 * ulp, XYZ_TOL)).all(), f
+        for f in ('r', 'g', 'b', 'tile'):
+            assert (got[f] == exp[f]).all(), f
+
+
 def test_downsample_random_volume(gpu, oracle):
     rng = np.random.default_rng(11)
     n = 200000
