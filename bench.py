@@ -51,6 +51,22 @@ def make_input(cwipc, npoints_arg: int, angle: float):
     return pc
 
 
+def measured_traffic(n_points: int, kernel: str):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes
+    (profiles/rNN_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this
+    bench, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the committed
+    numbers are for another workload or kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload_points") == n_points and d.get("kernel") == kernel:
+            return d.get("hbm_bytes_per_launch"), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 12.0):
     """Time the oracle's downsample on the host (1 thread).  Test infrastructure used as the CPU baseline."""
     from oracle import oracle
@@ -168,6 +184,8 @@ def main() -> None:
     algorithmic_bytes = 16 * n + 16 * n_out
     achieved = algorithmic_bytes / (dom_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = measured_traffic(n, dominant)
+
     if rank == 0:
         result = {
             "metric": "Mpoints/s filtered (voxel downsample, 10M-pt synthetic) + achieved HBM GB/s",
@@ -199,7 +217,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algorithmic_bytes,
                 "kernel_ms_avg": dom_ms,
                 "all_kernels_ms_per_step": all_ms,

@@ -1,0 +1,97 @@
+"""N > 1 on CPU: the all-gatherv join of cwipc_util_amd.multigpu over gloo, world sizes 2 and 3.
+
+The exchange function is device-agnostic (torch tensors of cwipc_point records as int32[n, 4]);
+on the GPU box the same code runs over RCCL.  The expected result is the reference's fold of
+cwipc_join over the tiles in tile order (reference python/cwipc/net/source_synchronizer.py:175-188),
+computed with the oracle.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tile_of_rank(rank: int, case: str):
+    """The cloud a rank contributes: (points, timestamp, cellsize, has_cloud)."""
+    from oracle import oracle
+    pts, cs = oracle.synthetic(20000 + 7000 * rank, 0.3 * rank)
+    if case == "tiles":
+        # every rank filters "its camera" out of its own capture
+        out = oracle.tilefilter(pts, 1 + (rank % 2))
+        out = out.copy()
+        out['tile'] = 1 << rank
+        return out, 1000 - rank, cs, True
+    if case == "voxelized":
+        out, ocs = oracle.downsample(pts, cs, 0.02)
+        return out, 500 + rank, ocs, True
+    if case == "ragged":
+        # rank 0 has no cloud this frame, rank 1 an empty one, later ranks real ones
+        if rank == 0:
+            return oracle.empty(0), 0, 0.0, False
+        if rank == 1:
+            return oracle.empty(0), 77, 0.5, True
+        return pts[: 1000 * rank + 3], 90 + rank, cs, True
+    raise ValueError(case)
+
+
+def _expected(world: int, case: str):
+    from oracle import oracle
+    fused, ts, cs = None, None, None
+    for r in range(world):
+        pts, t, c, has = _tile_of_rank(r, case)
+        if not has:
+            continue
+        if fused is None:
+            fused, ts, cs = pts, t, c
+        else:
+            fused, ts, cs = oracle.join(fused, pts), min(ts, t), min(cs, c)
+    if fused is None:
+        fused, ts, cs = oracle.empty(0), 0, 0.0
+    return fused, ts, cs
+
+
+def _worker(rank: int, world: int, port: int, case: str, result_dir: str):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from cwipc_util_amd.multigpu import all_gatherv_points, tiles_of_rank
+        pts, ts, cs, has = _tile_of_rank(rank, case)
+        local = torch.from_numpy(np.ascontiguousarray(pts).view(np.int32).reshape(-1, 4).copy())
+        fused, fts, fcs, counts = all_gatherv_points(local, ts, cs, has)
+        exp, ets, ecs = _expected(world, case)
+        got = fused.numpy().reshape(-1).view(exp.dtype) if fused.shape[0] else exp[:0]
+        assert counts == [len(_tile_of_rank(r, case)[0]) for r in range(world)], counts
+        assert len(got) == len(exp), (len(got), len(exp))
+        assert got.tobytes() == exp.tobytes(), "fused cloud differs from the cwipc_join fold"
+        assert fts == ets, (fts, ets)
+        assert fcs == pytest.approx(ecs, rel=0, abs=0), (fcs, ecs)
+        # tile -> rank mapping: round robin, every tile exactly once
+        owned = [tiles_of_rank(8, r, world) for r in range(world)]
+        assert sorted(t for o in owned for t in o) == list(range(8))
+        assert all(t % world == rank for t in owned[rank])
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "tiles"), (2, "voxelized"), (3, "ragged"), (2, "ragged")])
+def test_all_gatherv_join_gloo(tmp_path, world, case):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
