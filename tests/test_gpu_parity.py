@@ -472,3 +472,55 @@ def test_profile_records_kernels(gpu, synth):
         gpu.cwipc_downsample(pc, 0.01)
     assert "voxel_accumulate" in prof.kernels and prof.kernels["voxel_accumulate"][1] == 1
     assert prof.kernels["voxel_accumulate"][0] > 0
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full sizes (10 M points): direct comparison (the oracle needs ~1 s for the voxel
+# grid and ~40 s for the outlier filter) plus size-independent properties
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_cloud(oracle):
+    return oracle.synthetic(10_000_000, 0.0)
+
+
+def test_full_size_downsample(gpu, oracle, full_cloud):
+    pts, cs = full_cloud
+    assert len(pts) == 9998244
+    got, exp = check_downsample(gpu, oracle, pts, cs, 0.01)
+    assert len(got) == 39548
+    # properties: tile bits are conserved, the result is a fixed point of the filter (up to the
+    # final fp32 rounding of the centroid), every centroid lies inside the cloud's box
+    assert np.bitwise_or.reduce(got['tile']) == np.bitwise_or.reduce(pts['tile'])
+    again = gpu.cwipc_downsample(make_cloud(gpu, got, 0.01), 0.01).get_numpy_array()
+    assert len(again) == len(got)
+    for f in ('x', 'y', 'z'):
+        assert np.abs(again[f] - got[f]).max() <= 2.4e-7
+        assert pts[f].min() <= got[f].min() and got[f].max() <= pts[f].max()
+    assert (again['tile'] == got['tile']).all() and (again['r'] == got['r']).all()
+    check_downsample(gpu, oracle, pts, cs, -0.01)
+
+
+def test_full_size_downsample_is_order_independent(gpu, full_cloud):
+    """The plain grid emits voxels in index order, so any input order must give the same cloud;
+    the sums are integers, so the equality is exact (the reference's fp32 sums are not)."""
+    pts, cs = full_cloud
+    rng = np.random.default_rng(20260129)   # SURVEY section 8d: the supplemental permuted input
+    a = gpu.cwipc_downsample(make_cloud(gpu, pts, cs), -0.01).get_numpy_array()
+    b = gpu.cwipc_downsample(make_cloud(gpu, pts[rng.permutation(len(pts))], cs), -0.01).get_numpy_array()
+    assert same(a, b)
+
+
+def test_full_size_tilefilter_join(gpu, oracle, full_cloud):
+    pts, cs = full_cloud
+    pc = make_cloud(gpu, pts, cs, 7)
+    t1, t2 = gpu.cwipc_tilefilter(pc, 1), gpu.cwipc_tilefilter(pc, 2)
+    assert t1.count() == 4999122 and t2.count() == 4999122
+    assert same(t1.get_numpy_array(), oracle.tilefilter(pts, 1))
+    j = gpu.cwipc_join(t1, t2).get_numpy_array()
+    assert same(j, oracle.join(oracle.tilefilter(pts, 1), oracle.tilefilter(pts, 2)))
+
+
+def test_full_size_remove_outliers(gpu, oracle, full_cloud):
+    pts, cs = full_cloud
+    got, exp = check_sor(gpu, oracle, pts, cs, 16, 1.0)
+    assert 0 < len(got) < len(pts)
