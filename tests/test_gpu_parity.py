@@ -180,6 +180,20 @@ def test_colorize_large(gpu, oracle, synth):
 # ---------------------------------------------------------------------------
 # voxel downsample
 # ---------------------------------------------------------------------------
+def voxel_population(pts, leaf, out):
+    """Points of `pts` in the voxel (global lattice, fp32 arithmetic of pcl::VoxelGrid) each point of `out` lies in.
+    An upper bound for the octree path, where a voxel cut by a leaf face is emitted once per leaf."""
+    inv = np.float32(1.0) / np.float32(leaf)
+    def keys(a):
+        ijk = [np.floor(a[f] * inv).astype(np.int64) + (1 << 20) for f in ('x', 'y', 'z')]
+        return (ijk[2] << 42) | (ijk[1] << 21) | ijk[0]
+    uniq, cnt = np.unique(keys(pts), return_counts=True)
+    k = keys(out)
+    pos = np.clip(np.searchsorted(uniq, k), 0, len(uniq) - 1)
+    # a centroid that rounds onto a voxel face may land in the neighbour: treat it as crowded
+    return np.where(uniq[pos] == k, cnt[pos], len(pts))
+
+
 def check_downsample(gpu, oracle, pts, pc_cellsize, cellsize, ordered=True):
     pc = make_cloud(gpu, pts, pc_cellsize, 4242)
     out = gpu.cwipc_downsample(pc, cellsize)
@@ -191,17 +205,21 @@ def check_downsample(gpu, oracle, pts, pc_cellsize, cellsize, ordered=True):
     if not ordered:
         got = np.sort(got, order=['z', 'y', 'x'])
         exp = np.sort(exp, order=['z', 'y', 'x'])
-    # The bar is 1e-5 wherever a voxel holds at most a few hundred points (every BASELINE
-    # configuration: <= 254 points per voxel).  The reference algorithm keeps an fp32 running
-    # sum per voxel (pcl AccumulatorXYZ), whose own rounding error grows with the number of
-    # points in the voxel; the HIP path sums exact integers and rounds once.  For coarse
-    # cells (thousands of points per voxel) the bound therefore widens with that error model.
-    avg = len(pts) / max(len(exp), 1)
-    maxabs = max(float(np.abs(pts[f]).max()) for f in ('x', 'y', 'z')) if len(pts) else 0.0
-    tol = XYZ_TOL if avg <= 300 else max(XYZ_TOL, 8.0 * np.sqrt(avg) * 2.0 ** -24 * maxabs)
-    for f in ('x', 'y', 'z'):
-        err = np.abs(got[f].astype(np.float64) - exp[f].astype(np.float64)).max() if len(got) else 0.0
-        assert err <= tol, (f, err, tol)
+    # The bar is 1e-5 wherever a voxel holds at most a few hundred points (the typical voxel of every
+    # BASELINE configuration: 254 points on average at 10 M).  The reference algorithm keeps an fp32
+    # running sum per voxel (pcl AccumulatorXYZ), whose own rounding error grows with the number of
+    # points in the voxel; the HIP path sums exact integers and rounds once (see
+    # test_downsample_means_are_correctly_rounded).  For crowded voxels (coarse cells, or the apex of
+    # the synthetic shape where whole rows collapse into one voxel) the bound widens per voxel with
+    # that error model.
+    if len(exp):
+        pop = voxel_population(pts, max(abs(cellsize), pc_cellsize), exp)
+        maxabs = max(float(np.abs(pts[f]).max()) for f in ('x', 'y', 'z'))
+        tol = np.where(pop <= 300, XYZ_TOL, np.maximum(XYZ_TOL, 8.0 * np.sqrt(pop) * 2.0 ** -24 * maxabs))
+        for f in ('x', 'y', 'z'):
+            err = np.abs(got[f].astype(np.float64) - exp[f].astype(np.float64))
+            worst = int(np.argmax(err - tol))
+            assert (err <= tol).all(), (f, float(err[worst]), float(tol[worst]), int(pop[worst]))
     for f in ('r', 'g', 'b', 'tile'):
         assert (got[f] == exp[f]).all(), f
     return got, exp
@@ -488,16 +506,18 @@ def test_full_size_downsample(gpu, oracle, full_cloud):
     assert len(pts) == 9998244
     got, exp = check_downsample(gpu, oracle, pts, cs, 0.01)
     assert len(got) == 39548
-    # properties: tile bits are conserved, the result is a fixed point of the filter (up to the
-    # final fp32 rounding of the centroid), every centroid lies inside the cloud's box
     assert np.bitwise_or.reduce(got['tile']) == np.bitwise_or.reduce(pts['tile'])
-    again = gpu.cwipc_downsample(make_cloud(gpu, got, 0.01), 0.01).get_numpy_array()
+    # plain grid: besides the comparison, the result is a fixed point of the filter (up to the final
+    # fp32 rounding of a centroid) and every centroid lies inside the cloud's box.  (Not so on the
+    # octree path: a second pass anchors its leaves at another first point and cuts other voxels.)
+    got, exp = check_downsample(gpu, oracle, pts, cs, -0.01)
+    assert len(got) == 39312
+    again = gpu.cwipc_downsample(make_cloud(gpu, got, 0.01), -0.01).get_numpy_array()
     assert len(again) == len(got)
     for f in ('x', 'y', 'z'):
         assert np.abs(again[f] - got[f]).max() <= 2.4e-7
         assert pts[f].min() <= got[f].min() and got[f].max() <= pts[f].max()
     assert (again['tile'] == got['tile']).all() and (again['r'] == got['r']).all()
-    check_downsample(gpu, oracle, pts, cs, -0.01)
 
 
 def test_full_size_downsample_is_order_independent(gpu, full_cloud):
