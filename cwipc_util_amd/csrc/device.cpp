@@ -179,6 +179,46 @@ ThreadCtx::~ThreadCtx() {
 }
 
 // ---------------------------------------------------------------------------
+// event cache
+// ---------------------------------------------------------------------------
+namespace {
+std::mutex g_event_mutex;
+std::vector<hipEvent_t> g_event_cache;
+}  // namespace
+
+hipEvent_t event_get() {
+    {
+        std::lock_guard<std::mutex> lock(g_event_mutex);
+        if (!g_event_cache.empty()) {
+            hipEvent_t e = g_event_cache.back();
+            g_event_cache.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return e;
+}
+
+void event_put(hipEvent_t e) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lock(g_event_mutex);
+    g_event_cache.push_back(e);
+}
+
+void DeviceSoA::mark_pending(hipStream_t producer) {
+    ready = event_get();
+    // without an event the only safe thing is to finish the work now
+    if (!ready || hipEventRecord(ready, producer) != hipSuccess) {
+        (void)hipStreamSynchronize(producer);
+        if (ready) { event_put(ready); ready = nullptr; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // profiling
 // ---------------------------------------------------------------------------
 namespace {

@@ -59,8 +59,10 @@ bool device_available(const char *who);
 int current_device();
 
 // Device memory pool: size-classed free lists, never shrinks unless trimmed.
-// All library calls synchronise their stream before returning, so a block can
-// be reused by any stream as soon as it has been released.
+// Library calls synchronise their stream before returning, so a block can be reused by any
+// stream as soon as it has been released.  The one exception is a filter result whose last
+// kernel is still in flight when the call returns: it carries a `ready` event (DeviceSoA),
+// consumers make their stream wait for it, and its block is released only after the event.
 void *pool_alloc(size_t bytes);
 void pool_free(void *ptr);
 
@@ -82,6 +84,10 @@ struct ThreadCtx {
     ~ThreadCtx();
 };
 ThreadCtx &tctx();
+
+// Cached hipEvents without timing, for the `ready` marks of asynchronous results.
+hipEvent_t event_get();
+void event_put(hipEvent_t e);
 
 // Profiling: kernels are launched through CW_LAUNCH so that per-kernel device
 // time can be collected with hipEvents on the launching stream.
@@ -114,11 +120,27 @@ struct DeviceSoA {
     // anchored there); fetched from the device on demand otherwise.
     mutable bool has_first = false;
     mutable float first[3] = {0, 0, 0};
+    // Set (before the cloud is published) when the producing call returned with its last kernel
+    // still running: every consumer orders its stream after this event; never changed afterwards.
+    hipEvent_t ready = nullptr;
+    void mark_pending(hipStream_t producer);            // record `ready` on the producer's stream
+    void wait_on(hipStream_t consumer) const {          // device-side wait, no host blocking
+        if (ready) (void)hipStreamWaitEvent(consumer, ready, 0);
+    }
+    void wait_host() const {                            // for consumers outside the library's streams
+        if (ready) (void)hipEventSynchronize(ready);
+    }
     float *x() const { return (float *)base; }
     float *y() const { return (float *)base + stride; }
     float *z() const { return (float *)base + 2 * stride; }
     uint32_t *rgbt() const { return (uint32_t *)base + 3 * stride; }
-    ~DeviceSoA() { if (base) pool_free(base); }
+    ~DeviceSoA() {
+        if (ready) {
+            (void)hipEventSynchronize(ready);   // normally long complete
+            event_put(ready);
+        }
+        if (base) pool_free(base);
+    }
 };
 std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints);
 

@@ -75,6 +75,11 @@ constexpr int CELLS = GRID_DIM * GRID_DIM * GRID_DIM;   // 314432 < 2^19
 constexpr int CELL_BITS = 19;
 constexpr int BITWORDS = CELLS / 32;            // 9826 occupancy words per leaf grid (CELLS is a multiple of 32)
 constexpr uint32_t KEY_EMPTY = 0xffffffffu;
+// the finalize pass works on slices of a leaf's occupancy bitmap
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_SEGS = 8;
+constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 1229
+constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 5
 constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
 // Offsets are summed with a per-point bias so that the packed sums never borrow.  fl(f * inv_leaf)
 // may land |g| * 2^-23 voxels away from f / leaf, so an offset lies in [-|g| / 2, 2^22 + |g| / 2] units:
@@ -132,8 +137,7 @@ struct VoxWork {
     float *bboxes;                   // [nranges][6]
     const float *faces;              // [3][FACES] thresholds (positive cellsize only)
     uint32_t *bitmaps;               // [leaf hash][BITWORDS] occupancy of the leaf grids (bit = cell)
-    uint32_t *leaf_count;            // [leaf hash] occupied cells per leaf (accumulated by K1's flush)
-    uint32_t *seg_count;             // [leaf hash][RANK_SEGS] occupied cells per bitmap slice (seg_count_kernel)
+    uint32_t *seg_count;             // [leaf hash][RANK_SEGS] occupied cells per bitmap slice (accumulated by K1's flush)
 };
 
 inline __host__ __device__ uint64_t mix64(uint64_t k) {
@@ -220,6 +224,12 @@ __device__ __forceinline__ unsigned long long *record_ptr(const VoxWork &W, uint
     return W.records + ((size_t)(key >> CELL_BITS) * CELLS + (key & ((1u << CELL_BITS) - 1))) * RECORD_WORDS;
 }
 
+// index into seg_count of the bitmap slice that holds a record's bit
+__device__ __forceinline__ uint32_t slice_of(uint32_t key) {
+    const uint32_t cell = key & ((1u << CELL_BITS) - 1);
+    return (key >> CELL_BITS) * RANK_SEGS + (cell >> 5) / SEG_WORDS;
+}
+
 __device__ __forceinline__ void mark_occupied(const VoxWork &W, uint32_t key) {
     const uint32_t cell = key & ((1u << CELL_BITS) - 1);
     atomicOr(&W.bitmaps[(size_t)(key >> CELL_BITS) * BITWORDS + (cell >> 5)], 1u << (cell & 31u));
@@ -237,7 +247,7 @@ __device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t li
     atomicOr(&rec[7], (unsigned long long)tile);
     if ((old >> 32) == 0) {
         mark_occupied(W, key);
-        atomicAdd(&W.leaf_count[key >> CELL_BITS], 1u);
+        atomicAdd(&W.seg_count[slice_of(key)], 1u);
         const uint32_t idx = atomicAdd(&W.ctrl[C_COUNT], 1u);
         if (idx < list_cap) W.occupied[idx] = key;
         else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
@@ -272,7 +282,7 @@ struct LdsTable {
     unsigned long long d[LTAB];   // count | sum r << 16 | sum g << 40
     uint32_t fresh[LTAB];         // records this workgroup touched first
     float faces[3 * FACES];
-    uint32_t htag[64], hcnt[64];  // first touches per leaf of this workgroup (leaf id + 1, count)
+    uint32_t htag[64], hcnt[64];  // first touches per bitmap slice of this workgroup (slice + 1, count)
     uint32_t nfresh, fresh_base;
 };
 
@@ -664,15 +674,15 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         if (sub == 3 && (old >> 32) == 0) {
             L.fresh[atomicAdd(&L.nfresh, 1u)] = k;
             mark_occupied(W, k);
-            // occupied cells per leaf, aggregated per workgroup (a few leaves per workgroup)
-            const uint32_t leaf = k >> CELL_BITS, hs = leaf & 63u;
-            const uint32_t tag = atomicCAS(&L.htag[hs], 0u, leaf + 1u);
-            if (tag == 0u || tag == leaf + 1u) atomicAdd(&L.hcnt[hs], 1u);
-            else atomicAdd(&W.leaf_count[leaf], 1u);
+            // occupied cells per bitmap slice, aggregated per workgroup (a few slices per workgroup)
+            const uint32_t sl = slice_of(k), hs = sl & 63u;
+            const uint32_t tag = atomicCAS(&L.htag[hs], 0u, sl + 1u);
+            if (tag == 0u || tag == sl + 1u) atomicAdd(&L.hcnt[hs], 1u);
+            else atomicAdd(&W.seg_count[sl], 1u);
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.leaf_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
+    if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.seg_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
     const uint32_t nfresh = L.nfresh;
     if (threadIdx.x == 0 && nfresh) L.fresh_base = atomicAdd(&W.ctrl[C_COUNT], nfresh);
     __syncthreads();
@@ -691,8 +701,10 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 // ranges that do are re-read point by point.
 __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ z, const float *__restrict__ bboxes,
-                                                            uint32_t *__restrict__ ctrl) {
+                                                            uint32_t *__restrict__ ctrl, const unsigned long long *__restrict__ leaf_keys,
+                                                            uint32_t leaf_cap) {
     __shared__ double s_mn[3], s_mx[3];
+    __shared__ int s_resolved;
     __shared__ int s_depth;
     __shared__ long long s_shift[3];
     __shared__ unsigned long long s_first;
@@ -752,6 +764,20 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
     __syncthreads();
 
     const double eps = (double)FLT_EPSILON;
+    // one step of adoptBoundingBoxToPoint's loop: double the box, keeping the corner on the axes in `up`
+    auto grow = [&](const bool up[3]) {
+        double side = (double)(1u << s_depth) * P.res;
+        for (int a = 0; a < 3; a++) {
+            if (!up[a]) {
+                s_mn[a] -= side;
+                s_shift[a] += (long long)1 << s_depth;   // existing keys move up on this axis
+            }
+        }
+        s_depth++;
+        side = (double)(1u << s_depth) * P.res - eps;
+        for (int a = 0; a < 3; a++) s_mx[a] = s_mn[a] + side;
+        s_events++;
+    };
     uint32_t range = 0;
     while (range < nranges) {
         // first range >= `range` whose box sticks out of the current octree box
@@ -759,18 +785,51 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         __syncthreads();
         {
             const double mn0 = s_mn[0], mn1 = s_mn[1], mn2 = s_mn[2], mx0 = s_mx[0], mx1 = s_mx[1], mx2 = s_mx[2];
+            uint32_t mine = 0xffffffffu;
             for (uint32_t c = range + tid; c < nranges; c += 1024) {
                 float b[6];
                 for (int i = 0; i < 6; i++) b[i] = cached ? s_boxes[c * 6 + i] : bboxes[(size_t)c * 6 + i];
                 const bool viol = (double)b[0] < mn0 || (double)b[1] < mn1 || (double)b[2] < mn2 ||
                                   (double)b[3] >= mx0 || (double)b[4] >= mx1 || (double)b[5] >= mx2;
-                if (viol) { atomicMin(&s_first, (unsigned long long)c); break; }
+                if (viol) { mine = c; break; }
             }
+            // one LDS atomic per wave, not per lane: after a growth step most ranges still stick out
+            for (int off = 32; off > 0; off >>= 1) mine = min(mine, (uint32_t)__shfl_xor((int)mine, off, 64));
+            if ((tid & 63) == 0 && mine != 0xffffffffu) atomicMin(&s_first, (unsigned long long)mine);
         }
         __syncthreads();
         const unsigned long long hit = s_first;
         __syncthreads();
         if (hit == ~0ull) break;
+
+        // Shortcut on the range's box: a point triggers growth when it violates the octree box, and the
+        // step it takes depends only on the axes where it lies above the box.  If the range sticks out
+        // below only, or above on exactly one axis and nowhere below, every triggering point of the range
+        // has the same pattern, so the steps follow from the box of the range without reading its points.
+        if (tid == 0) {
+            float b[6];
+            for (int i = 0; i < 6; i++) b[i] = cached ? s_boxes[hit * 6 + i] : bboxes[(size_t)hit * 6 + i];
+            int resolved = 0;
+            for (;;) {
+                bool up[3], any_low = false;
+                int n_up = 0;
+                for (int a = 0; a < 3; a++) {
+                    up[a] = (double)b[3 + a] >= s_mx[a];
+                    n_up += up[a] ? 1 : 0;
+                    any_low |= (double)b[a] < s_mn[a];
+                }
+                if (n_up == 0 && !any_low) { resolved = 1; break; }
+                if (!(n_up == 0 || (n_up == 1 && !any_low))) break;   // mixed patterns: replay point by point
+                if (s_depth >= 31) { atomicOr(&ctrl[C_ERR], ERR_DEPTH); resolved = 1; break; }
+                grow(up);
+            }
+            s_resolved = resolved;
+        }
+        __syncthreads();
+        if (s_resolved) {
+            range = (uint32_t)hit + 1;
+            continue;
+        }
 
         // replay that range in index order, a tile of 4096 points at a time
         const size_t r_lo = (size_t)hit * P.per_wave;
@@ -790,14 +849,18 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
                 __syncthreads();
                 {
                     const double mn0 = s_mn[0], mn1 = s_mn[1], mn2 = s_mn[2], mx0 = s_mx[0], mx1 = s_mx[1], mx2 = s_mx[2];
+                    unsigned long long mine = ~0ull;
                     for (int j = 0; j < 4; j++) {
                         const size_t idx = base + j;
                         if (idx < from || idx >= r_hi) continue;
                         if (!(isfinite(qx[j]) && isfinite(qy[j]) && isfinite(qz[j]))) continue;
                         const bool viol = (double)qx[j] < mn0 || (double)qy[j] < mn1 || (double)qz[j] < mn2 ||
                                           (double)qx[j] >= mx0 || (double)qy[j] >= mx1 || (double)qz[j] >= mx2;
-                        if (viol) { atomicMin(&s_first, (unsigned long long)idx); break; }
+                        if (viol) { mine = (unsigned long long)idx; break; }
                     }
+                    // lanes hold ascending indices: the lowest lane with a violation has the wave's minimum
+                    const unsigned long long vote = __ballot(mine != ~0ull);
+                    if (vote != 0ull && (tid & 63) == __ffsll((long long)vote) - 1) atomicMin(&s_first, mine);
                 }
                 __syncthreads();
                 const unsigned long long pidx = s_first;
@@ -818,17 +881,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
                         }
                         if (!any) break;
                         if (s_depth >= 31) { atomicOr(&ctrl[C_ERR], ERR_DEPTH); break; }
-                        double side = (double)(1u << s_depth) * P.res;
-                        for (int a = 0; a < 3; a++) {
-                            if (!up[a]) {
-                                s_mn[a] -= side;
-                                s_shift[a] += (long long)1 << s_depth;   // existing keys move up on this axis
-                            }
-                        }
-                        s_depth++;
-                        side = (double)(1u << s_depth) * P.res - eps;
-                        for (int a = 0; a < 3; a++) s_mx[a] = s_mn[a] + side;
-                        s_events++;
+                        grow(up);
                     }
                 }
                 from = (size_t)pidx + 1;
@@ -836,6 +889,26 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
             }
         }
         range = (uint32_t)hit + 1;
+    }
+    // the finalize pass orders leaves by the Morton code of their final keys: check here that it can
+    // (depth, key range), so that it has no error of its own to report
+    __syncthreads();
+    {
+        const int depth = s_depth;
+        if (depth > 14) {
+            if (tid == 0) atomicOr(&ctrl[C_ERR], ERR_DEPTH);
+        } else {
+            bool bad = false;
+            for (uint32_t q = tid; q < leaf_cap; q += 1024) {
+                const unsigned long long lp = leaf_keys[q];
+                if (lp == 0ull) continue;
+                for (int a = 0; a < 3; a++) {
+                    const long long lk = (long long)unpack_leaf(lp, a) + s_shift[a];
+                    bad |= lk < 0 || lk >= ((long long)1 << depth);
+                }
+            }
+            if (bad) atomicOr(&ctrl[C_ERR], ERR_LEAF_RANGE);
+        }
     }
     if (tid == 0) {
         ctrl[C_DEPTH] = (uint32_t)s_depth;
@@ -987,10 +1060,6 @@ __device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W
 // of the leaf (cells of all leaves that precede it in Morton order) + occupied cells in the
 // earlier slices, ranks of the slice's cells from a popcount scan, then gather, emit and clean.
 // Replaces the key sort: no pass over the outputs other than the emit itself.
-constexpr int RANK_THREADS = 256;
-constexpr int RANK_SEGS = 8;
-constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 1229
-constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 5
 
 __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, VoxWork W, uint32_t leaf_cap, uint32_t m, uint32_t *order,
                                                                  float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
@@ -1015,10 +1084,14 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
     for (uint32_t q = threadIdx.x; q < leaf_cap; q += RANK_THREADS) {
         const unsigned long long lq = W.leaf_keys[q];
         unsigned long long other;
-        if (lq != 0ull && q != p && leaf_morton(W, lq, depth, other) && other < mine) before += W.leaf_count[q];
+        if (lq != 0ull && q != p && leaf_morton(W, lq, depth, other) && other < mine) {
+            const uint4 *sc = reinterpret_cast<const uint4 *>(W.seg_count + (size_t)q * RANK_SEGS);
+            const uint4 s0 = sc[0], s1 = sc[1];
+            before += s0.x + s0.y + s0.z + s0.w + s1.x + s1.y + s1.z + s1.w;
+        }
     }
     // earlier slices may already have been cleaned by their own workgroups, so their cells are
-    // counted from the snapshot seg_count_kernel took before any cleaning started
+    // counted from the per-slice totals K1 accumulated, not from the bitmaps
     for (uint32_t sg = threadIdx.x; sg < seg; sg += RANK_THREADS) before += W.seg_count[p * RANK_SEGS + sg];
     for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
     if (lane == 0) wave_tot[wave] = before;
@@ -1075,22 +1148,6 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
     }
 }
 
-// Occupied cells per bitmap slice, taken before rank_emit starts cleaning.
-__global__ void __launch_bounds__(256) seg_count_kernel(VoxWork W) {
-    __shared__ uint32_t wsum[4];
-    const uint32_t p = blockIdx.x / RANK_SEGS, seg = blockIdx.x % RANK_SEGS;
-    uint32_t c = 0;
-    if (W.leaf_keys[p] != 0ull) {
-        const uint32_t *bm = W.bitmaps + (size_t)p * BITWORDS;
-        const int w_lo = (int)seg * SEG_WORDS, w_hi = min(w_lo + SEG_WORDS, BITWORDS);
-        for (int w = w_lo + threadIdx.x; w < w_hi; w += 256) c += __popc(bm[w]);
-    }
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) W.seg_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
 // ---------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------
@@ -1099,28 +1156,30 @@ struct Workspace {
     uint32_t leaf_cap = 0;     // leaf hash capacity = number of grids (power of two)
     size_t list_cap = 0;
     size_t bbox_cap = 0;
+    void *head = nullptr;              // ctrl | leaf_keys | seg_count, one block so that one memset resets it
+    size_t head_bytes = 0;
     unsigned long long *leaf_keys = nullptr;
     unsigned long long *records = nullptr;
     uint32_t *occupied = nullptr;
+    uint32_t *order = nullptr;         // records in output order (finalize pass), list_cap entries
     float *bboxes = nullptr;
     uint32_t *ctrl = nullptr;
     uint32_t *bitmaps = nullptr;
-    uint32_t *leaf_count = nullptr;
+    uint32_t *seg_count = nullptr;
     float *faces = nullptr;            // device copy of the threshold table
     float faces_host[3 * FACES];       // what the device copy holds
     bool faces_valid = false;
     void release() {
         // also runs at thread exit, when the runtime may be gone: errors ignored
-        if (leaf_keys) (void)hipFree(leaf_keys);
+        if (head) (void)hipFree(head);
         if (records) (void)hipFree(records);
         if (occupied) (void)hipFree(occupied);
+        if (order) (void)hipFree(order);
         if (bboxes) (void)hipFree(bboxes);
-        if (ctrl) (void)hipFree(ctrl);
         if (faces) (void)hipFree(faces);
         if (bitmaps) (void)hipFree(bitmaps);
-        if (leaf_count) (void)hipFree(leaf_count);
-        bitmaps = nullptr; leaf_count = nullptr;
-        leaf_keys = nullptr; records = nullptr; occupied = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
+        bitmaps = nullptr; seg_count = nullptr; head = nullptr; head_bytes = 0;
+        leaf_keys = nullptr; records = nullptr; occupied = nullptr; order = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
         leaf_cap = 0; list_cap = 0; bbox_cap = 0;
         faces_valid = false;
     }
@@ -1130,6 +1189,7 @@ struct Workspace {
 thread_local Workspace t_ws;
 
 constexpr size_t GRID_BYTES = (size_t)CELLS * RECORD_WORDS * 8;   // 20.1 MB per leaf grid
+constexpr size_t HEAD_CTRL_BYTES = 256;                           // C_WORDS words, padded
 
 bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nranges, hipStream_t s) {
     const int dev = current_device();
@@ -1144,23 +1204,28 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         ws.device = dev;
     }
     if (ws.leaf_cap < leaf_cap) {
-        if (ws.leaf_keys) (void)hipFree(ws.leaf_keys);
+        if (ws.head) (void)hipFree(ws.head);
         if (ws.records) (void)hipFree(ws.records);
         if (ws.bitmaps) (void)hipFree(ws.bitmaps);
-        if (ws.leaf_count) (void)hipFree(ws.leaf_count);
-        ws.leaf_keys = nullptr; ws.records = nullptr; ws.bitmaps = nullptr; ws.leaf_count = nullptr; ws.leaf_cap = 0;
-        CW_HIP_TRY(hipMalloc((void **)&ws.leaf_keys, (size_t)leaf_cap * 8));
+        ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr;
+        ws.records = nullptr; ws.bitmaps = nullptr; ws.leaf_cap = 0;
+        ws.head_bytes = HEAD_CTRL_BYTES + (size_t)leaf_cap * 8 + (size_t)leaf_cap * RANK_SEGS * sizeof(uint32_t);
+        CW_HIP_TRY(hipMalloc(&ws.head, ws.head_bytes));
+        ws.ctrl = (uint32_t *)ws.head;
+        ws.leaf_keys = (unsigned long long *)((char *)ws.head + HEAD_CTRL_BYTES);
+        ws.seg_count = (uint32_t *)((char *)ws.head + HEAD_CTRL_BYTES + (size_t)leaf_cap * 8);
         CW_HIP_TRY(hipMalloc((void **)&ws.bitmaps, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t)));
         CW_HIP_TRY(hipMemsetAsync(ws.bitmaps, 0, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t), s));
-        CW_HIP_TRY(hipMalloc((void **)&ws.leaf_count, (size_t)leaf_cap * (1 + RANK_SEGS) * sizeof(uint32_t)));   // leaf counts, then slice counts
         CW_HIP_TRY(hipMalloc((void **)&ws.records, (size_t)leaf_cap * GRID_BYTES));
         CW_HIP_TRY(hipMemsetAsync(ws.records, 0, (size_t)leaf_cap * GRID_BYTES, s));   // once; K4 keeps it clean afterwards
         ws.leaf_cap = leaf_cap;
     }
     if (ws.list_cap < n) {
         if (ws.occupied) (void)hipFree(ws.occupied);
-        ws.occupied = nullptr; ws.list_cap = 0;
+        if (ws.order) (void)hipFree(ws.order);
+        ws.occupied = nullptr; ws.order = nullptr; ws.list_cap = 0;
         CW_HIP_TRY(hipMalloc((void **)&ws.occupied, n * sizeof(uint32_t)));
+        CW_HIP_TRY(hipMalloc((void **)&ws.order, n * sizeof(uint32_t)));
         ws.list_cap = n;
     }
     if (ws.bbox_cap < nranges) {
@@ -1169,7 +1234,6 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipMalloc((void **)&ws.bboxes, (size_t)nranges * 6 * sizeof(float)));
         ws.bbox_cap = nranges;
     }
-    if (!ws.ctrl) CW_HIP_TRY(hipMalloc((void **)&ws.ctrl, C_WORDS * sizeof(uint32_t)));
     if (!ws.faces) CW_HIP_TRY(hipMalloc((void **)&ws.faces, 3 * FACES * sizeof(float)));
     return true;
 }
@@ -1254,11 +1318,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
-        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.leaf_count, ws.leaf_count + ws.leaf_cap};
+        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count};
 
-        bool ok = hipMemsetAsync(ws.ctrl, 0, C_WORDS * sizeof(uint32_t), c.stream) == hipSuccess &&
-                  hipMemsetAsync(ws.leaf_keys, 0, (size_t)ws.leaf_cap * 8, c.stream) == hipSuccess &&
-                  hipMemsetAsync(ws.leaf_count, 0, (size_t)ws.leaf_cap * sizeof(uint32_t), c.stream) == hipSuccess;
+        bool ok = hipMemsetAsync(ws.head, 0, ws.head_bytes, c.stream) == hipSuccess;   // control words, leaf table, slice counts
         if (ok && mode == 1 && !(ws.faces_valid && memcmp(ws.faces_host, faces_host, sizeof(faces_host)) == 0)) {
             float *stage = (float *)c.staging(sizeof(faces_host));
             ok = stage != nullptr;
@@ -1293,7 +1355,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                       src.y(), src.z(), src.rgbt(), W);
         }
         const size_t replay_lds = (leaf_split && nwaves <= REPLAY_LDS_RANGES) ? nwaves * 6 * sizeof(float) : 0;
-        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), replay_lds, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl);
+        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), replay_lds, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
+                  ws.leaf_keys, ws.leaf_cap);
         ok = hipMemcpyAsync(c.host_words, ws.ctrl, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
         ok = c.sync() && ok;
         if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
@@ -1309,21 +1372,18 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
 
         bool ranked = false;
         if (!err && m && leaf_split) {
-            // octree path: rank the occupied cells through the bitmaps, emit, clean -- no sort
+            // octree path: rank the occupied cells through the bitmaps, emit, clean -- no sort.  The
+            // replay kernel has already checked everything this pass could trip over, so the call
+            // returns with it in flight: the result carries a `ready` event, later work of this thread
+            // (including the next call's use of the workspace) is ordered behind it on the stream.
             dst = soa_alloc(m);
-            uint32_t *order_buf = (uint32_t *)pool_alloc((size_t)m * sizeof(uint32_t));
-            if (!dst || !order_buf) {
+            if (!dst) {
                 err |= 0x80000000u;
-                pool_free(order_buf);
             } else {
-                CW_LAUNCH("seg_count", seg_count_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(256), 0, c.stream, W);
-                CW_LAUNCH("rank_emit", rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, m, order_buf,
+                CW_LAUNCH("rank_emit", rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, m, ws.order,
                           dst->x(), dst->y(), dst->z(), dst->rgbt());
-                ok = hipMemcpyAsync(c.host_words, ws.ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
-                ok = c.sync() && ok;
-                if (ok) err |= c.host_words[C_ERR];
-                ranked = ok && !err;
-                pool_free(order_buf);
+                dst->mark_pending(c.stream);
+                ranked = true;
             }
         }
         if (!err && m && !leaf_split) {

@@ -186,6 +186,7 @@ int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, b
     if (!c.ensure()) return -1;
     void *aos = pool_alloc(need);
     if (!aos) return -1;
+    dev->wait_on(c.stream);
     k::soa_to_aos(*dev, (cwipc_point *)aos, m_npoints, c.stream);
     void *stage = c.staging(need);
     bool ok = stage != nullptr;
@@ -277,7 +278,14 @@ void cwipc_hip_pointcloud::adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t
 // H2D: pinned staging -> device AoS -> de-interleave kernel -> SoA planes.
 std::shared_ptr<DeviceSoA> cwipc_hip_pointcloud::device_points() {
     std::lock_guard<std::mutex> lock(m_lock);
-    if (m_dev && m_dev->device == current_device()) return m_dev;
+    if (m_dev && m_dev->device == current_device()) {
+        if (m_dev->ready) {   // result of a call whose last kernel may still be running: order this thread's stream after it
+            ThreadCtx &c = tctx();
+            if (!c.ensure()) return nullptr;
+            m_dev->wait_on(c.stream);
+        }
+        return m_dev;
+    }
     if (!m_has_data) return nullptr;
     if (!device_available("cwipc_pointcloud")) return nullptr;
     ThreadCtx &c = tctx();
@@ -634,6 +642,7 @@ extern "C" int cwipc_hip_device_planes(cwipc_pointcloud *pc, const float **x, co
     if (!ours) return -1;
     auto dev = ours->device_points();
     if (!dev) return -1;
+    dev->wait_host();   // the caller's streams are not ours: hand out finished data only
     if (x) *x = dev->x();
     if (y) *y = dev->y();
     if (z) *z = dev->z();
