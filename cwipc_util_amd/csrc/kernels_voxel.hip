@@ -427,17 +427,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     extern __shared__ __align__(16) unsigned char k1_smem[];
     LdsTable &L = *reinterpret_cast<LdsTable *>(k1_smem);
 
-    for (int i = threadIdx.x; i < LTAB; i += K1_THREADS) {
-        L.key[i] = KEY_EMPTY; L.tile[i] = 0;
-        L.a[i] = 0; L.b[i] = 0; L.c[i] = 0; L.d[i] = 0;
-    }
-    if (MODE == 1) {
-        for (int i = threadIdx.x; i < 3 * FACES; i += K1_THREADS) L.faces[i] = W.faces[i];
-    }
-    if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) L.nfresh = 0;
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     // everything that is the same for the whole wave lives in SGPRs
     const uint32_t range = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * K1_WAVES + (threadIdx.x >> 6)));
@@ -451,6 +440,21 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     const float4 *vy = reinterpret_cast<const float4 *>(y + lo) + lane;
     const float4 *vz = reinterpret_cast<const float4 *>(z + lo) + lane;
     const uint4 *vw = reinterpret_cast<const uint4 *>(rgbt + lo) + lane;
+    // the first step's loads go out before the table is initialised: their latency hides behind it
+    float4 cx = make_float4(0, 0, 0, 0), cy = cx, cz = cx;
+    uint4 cw = make_uint4(0, 0, 0, 0);
+    if (npts > 0) { cx = vx[0]; cy = vy[0]; cz = vz[0]; cw = vw[0]; }
+
+    for (int i = threadIdx.x; i < LTAB; i += K1_THREADS) {
+        L.key[i] = KEY_EMPTY; L.tile[i] = 0;
+        L.a[i] = 0; L.b[i] = 0; L.c[i] = 0; L.d[i] = 0;
+    }
+    if (MODE == 1) {
+        for (int i = threadIdx.x; i < 3 * FACES; i += K1_THREADS) L.faces[i] = W.faces[i];
+    }
+    if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) L.nfresh = 0;
+    __syncthreads();
 
     // wave-uniform caches: two leaf faces per axis, the last leaf and its id
     FaceCache fc0, fc1, fc2;
@@ -459,10 +463,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     int cl0 = 0, cl1 = 0, cl2 = 0;
     uint32_t cache_id = 0xffffffffu;
     bool cache_valid = false;
-
-    float4 cx = make_float4(0, 0, 0, 0), cy = cx, cz = cx;
-    uint4 cw = make_uint4(0, 0, 0, 0);
-    if (npts > 0) { cx = vx[0]; cy = vy[0]; cz = vz[0]; cw = vw[0]; }
 
 #pragma unroll 1
     for (int off = 0; off < npts; off += WAVE_STEP) {
@@ -643,12 +643,21 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     }
 
     // ---- flush: 8 lanes per table entry update one 64-byte record with returning adds ----
+    // All adds of a lane are issued before the first result is looked at, so that their round
+    // trips overlap (this is the serial tail of the kernel: nothing else is in flight any more).
     __syncthreads();
     const int sub = threadIdx.x & 7;
-#pragma unroll 1
-    for (int e = threadIdx.x >> 3; e < LTAB; e += K1_THREADS / 8) {
-        const uint32_t k = L.key[e];
-        if (k == KEY_EMPTY || (P.ablate & 8u)) continue;
+    constexpr int FLUSH_ITERS = LTAB / (K1_THREADS / 8);
+    uint32_t fkey[FLUSH_ITERS];
+    unsigned long long fold[FLUSH_ITERS];
+#pragma unroll
+    for (int it = 0; it < FLUSH_ITERS; it++) {
+        const int e = (threadIdx.x >> 3) + it * (K1_THREADS / 8);
+        uint32_t k = L.key[e];
+        if (P.ablate & 8u) k = KEY_EMPTY;
+        fkey[it] = k;
+        fold[it] = ~0ull;
+        if (k == KEY_EMPTY) continue;
         const uint32_t t = L.tile[e];
         const unsigned long long ea = L.a[e], eb = L.b[e], ec = L.c[e], ed = L.d[e];
         const unsigned long long cnt = ed & 0xffffull, bias = cnt * P.q_bias;
@@ -669,12 +678,15 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             break;
         default: val = 0; break;
         }
-        unsigned long long *rec = record_ptr(W, k);
-        const unsigned long long old = atomicAdd(&rec[sub], val);
-        if (sub == 3 && (old >> 32) == 0) {
+        fold[it] = atomicAdd(&record_ptr(W, k)[sub], val);
+    }
+#pragma unroll
+    for (int it = 0; it < FLUSH_ITERS; it++) {
+        const uint32_t k = fkey[it];
+        if (sub == 3 && k != KEY_EMPTY && (fold[it] >> 32) == 0) {
+            // first touch of this record in this call: list it, set its bit, count it in its bitmap slice
             L.fresh[atomicAdd(&L.nfresh, 1u)] = k;
             mark_occupied(W, k);
-            // occupied cells per bitmap slice, aggregated per workgroup (a few slices per workgroup)
             const uint32_t sl = slice_of(k), hs = sl & 63u;
             const uint32_t tag = atomicCAS(&L.htag[hs], 0u, sl + 1u);
             if (tag == 0u || tag == sl + 1u) atomicAdd(&L.hcnt[hs], 1u);
