@@ -88,7 +88,7 @@ constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per vox
 // finer than the spacing of fp32 coordinates out there).
 constexpr float FIX_ONE_WIDE_F = 16384.0f;
 constexpr uint32_t Q_BIAS = 1u << 21, Q_BIAS_WIDE = 1u << 19;
-constexpr float G_CHECK = 4.0e6f;
+constexpr float G_CHECK = 4.0e6f, G_CHECK_WIDE = 33554432.0f;
 constexpr int RECORD_WORDS = 8;                // 64-byte records: sx sy sz cr gb tlo thi tor
 constexpr int FACES = 128;                     // leaf faces per axis with a precomputed threshold
 constexpr int FACE_BACK = 63;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t li
 // One run of points of the same voxel, 32-bit in-wave form (at most 256 points).
 struct Run32 {
     uint32_t key;       // leaf id << 19 | cell, KEY_EMPTY = none
-    int qx, qy, qz;     // fixed-point offsets inside the voxel
+    uint32_t qx, qy, qz;   // sums of biased fixed-point offsets inside the voxel
     uint32_t cr;        // count << 16 | sum r
     uint32_t gb;        // sum g << 16 | sum b
     uint32_t tile;
@@ -294,6 +294,7 @@ struct K1Params {
     int fb0, fb1, fb2;
     uint32_t leaf_mask, list_cap, ablate;
     uint32_t q_bias;    // per-point bias of the offset sums
+    float q_round;      // q_bias + 0.5 (the offset is biased and rounded by one fma, then truncated)
     float g_check;      // |coordinate * inv_leaf| a wave may see at this scale (inf: no limit)
     double mn0[3];      // MODE 2 only
     double res;
@@ -303,29 +304,38 @@ __device__ __forceinline__ unsigned long long u64_of(uint32_t lo, uint32_t hi) {
 
 // Add one run to the workgroup table.  All in-wave sums are 32-bit (<= 256 points), so the four
 // packed 64-bit addends are assembled from 32-bit halves.
-__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32_t list_cap, uint32_t q_bias, const Run32 &r) {
+__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32_t list_cap, uint32_t q_bias, const Run32 &r, bool active) {
+    // Called by the whole wave (active = this lane has something to insert).  The slot search is a loop
+    // of its own, so that the adds are issued once per call however many probes the unluckiest lane needs:
+    // LDS atomics are the scarcest resource of this kernel.
     uint32_t slot = (r.key * 0x9E3779B1u) >> (32 - 11);   // LTAB = 2^11
-    const uint32_t cnt = r.cr >> 16, bias = cnt * q_bias;   // every q + q_bias is >= 0, so the sums fit unsigned 32 bits
-    const unsigned long long A = u64_of((uint32_t)(r.qx + (int)bias), 0u);
-    const unsigned long long B = u64_of((uint32_t)(r.qy + (int)bias), 0u);
-    const unsigned long long C = u64_of((uint32_t)(r.qz + (int)bias), (r.gb & 0xffffu) << 8);                     // | sum b << 40
-    const unsigned long long D = u64_of(__builtin_amdgcn_alignbit(r.cr, r.cr, 16), (r.gb >> 16) << 8);           // count | sum r << 16 | sum g << 40
-    bool done = false;
+    bool pending = active;
+#pragma unroll 1
     for (int probe = 0; probe < LTAB_PROBES; probe++) {
-        const uint32_t old = atomicCAS(&L.key[slot], KEY_EMPTY, r.key);
-        if (old == KEY_EMPTY || old == r.key) {
-            atomicAdd(&L.a[slot], A);
-            atomicAdd(&L.b[slot], B);
-            atomicAdd(&L.c[slot], C);
-            atomicAdd(&L.d[slot], D);
-            atomicOr(&L.tile[slot], r.tile);
-            done = true;
-            break;
+        if (pending) {
+            const uint32_t old = atomicCAS(&L.key[slot], KEY_EMPTY, r.key);
+            if (old == KEY_EMPTY || old == r.key) pending = false;
+            else slot = (slot + 1) & (LTAB - 1);
         }
-        slot = (slot + 1) & (LTAB - 1);
+        if (__ballot(pending) == 0ull) break;
     }
-    if (!done) {
-        global_insert_lane(W, list_cap, r.key, r.qx, r.qy, r.qz, u64_of(r.cr & 0xffffu, cnt), u64_of(r.gb & 0xffffu, r.gb >> 16), r.tile);
+    if (active && !pending) {
+        // every offset carries its bias already, so the in-wave sums are plain unsigned 32-bit numbers
+        atomicAdd(&L.a[slot], u64_of(r.qx, 0u));
+        atomicAdd(&L.b[slot], u64_of(r.qy, 0u));
+        atomicAdd(&L.c[slot], u64_of(r.qz, (r.gb & 0xffffu) << 8));                                            // | sum b << 40
+        atomicAdd(&L.d[slot], u64_of(__builtin_amdgcn_alignbit(r.cr, r.cr, 16), (r.gb >> 16) << 8));         // count | sum r << 16 | sum g << 40
+    }
+    // the tile bits of a voxel are almost always there already: a plain read is much cheaper than an atomic
+    const bool need_or = active && !pending && (L.tile[slot] & r.tile) != r.tile;
+    if (__ballot(need_or) != 0ull) {
+        if (need_or) atomicOr(&L.tile[slot], r.tile);
+    }
+    if (active && pending) {   // table saturated (incoherent input): straight to the global records
+        const uint32_t cnt = r.cr >> 16;
+        const long long bias = (long long)cnt * q_bias;
+        global_insert_lane(W, list_cap, r.key, (long long)r.qx - bias, (long long)r.qy - bias, (long long)r.qz - bias, u64_of(r.cr & 0xffffu, cnt),
+                           u64_of(r.gb & 0xffffu, r.gb >> 16), r.tile);
     }
 }
 
@@ -339,16 +349,15 @@ __device__ __forceinline__ int dpp_shl(int v) {   // lane l reads lane l + N
     return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xf, 0xf, true);
 }
 
-// one step of the segmented inclusive scan (branch-free: a set flag masks the incoming value)
+// one step of the segmented inclusive scan: lanes that start a segment keep their value
 template <int N>
 __device__ __forceinline__ void scan_step(Run32 &v, int &flag) {
-    const int keep = flag ? 0 : -1;
-    v.qx += dpp_shr<N>(v.qx) & keep;
-    v.qy += dpp_shr<N>(v.qy) & keep;
-    v.qz += dpp_shr<N>(v.qz) & keep;
-    v.cr += (uint32_t)(dpp_shr<N>((int)v.cr) & keep);
-    v.gb += (uint32_t)(dpp_shr<N>((int)v.gb) & keep);
-    v.tile |= (uint32_t)(dpp_shr<N>((int)v.tile) & keep);
+    const bool keep = flag != 0;
+    const uint32_t qx = v.qx + (uint32_t)dpp_shr<N>((int)v.qx), qy = v.qy + (uint32_t)dpp_shr<N>((int)v.qy), qz = v.qz + (uint32_t)dpp_shr<N>((int)v.qz);
+    const uint32_t cr = v.cr + (uint32_t)dpp_shr<N>((int)v.cr), gb = v.gb + (uint32_t)dpp_shr<N>((int)v.gb);
+    const uint32_t tile = v.tile | (uint32_t)dpp_shr<N>((int)v.tile);
+    v.qx = keep ? v.qx : qx; v.qy = keep ? v.qy : qy; v.qz = keep ? v.qz : qz;
+    v.cr = keep ? v.cr : cr; v.gb = keep ? v.gb : gb; v.tile = keep ? v.tile : tile;
     flag |= dpp_shr<N>(flag);
 }
 
@@ -356,69 +365,76 @@ __device__ __forceinline__ void scan_step(Run32 &v, int &flag) {
 struct FaceCache {
     int mc;
     float tlo, thi;
+    int cb;   // voxel index (of floor(p * inv_leaf)) that is cell 0 of leaf mc - 1:  ib + 64 * (mc - 1) - 2
 };
 
 struct PointOut {
     uint32_t key;   // cell inside the leaf grid, KEY_EMPTY if the point is skipped
-    int l0, l1, l2; // leaf lattice coordinates
-    int q0, q1, q2; // fixed-point offsets
-    bool seen;      // the point exists and is finite (whatever the face caches say)
+    uint32_t nn;    // MODE 1: leaf relative to the cached faces, n0 | n1 << 2 | n2 << 4 with leaf_a = mc_a - 1 + n_a
+    int l0, l1, l2; // MODE 0 / 2: leaf lattice coordinates
+    uint32_t q0, q1, q2; // biased fixed-point offsets inside the voxel (>= 0)
+    int u0, u1, u2; // MODE 1: voxel index relative to cb (window test)
+    bool seen;      // the point exists and is finite
 };
 
+// One coordinate: cell c inside the leaf grid, leaf (n or l), biased offset q.
 // MODE 0: plain grid (bricks on the voxel lattice); 1: octree leaves by face thresholds; 2: octree leaves by f64 division.
 template <int MODE>
-__device__ __forceinline__ void axis_cell(const K1Params &P, int ib, const FaceCache &fc, int axis, float f, bool &good, bool &miss, int &t_out,
-                                          int &l, int &c, int &q) {
-    float g = floorf(__fmul_rn(f, P.inv_leaf));   // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
-    good &= fabsf(g) < 33554432.0f;               // false for NaN / Inf / points beyond 2^25 voxels
-    g = __builtin_amdgcn_fmed3f(g, -33554432.0f, 33554432.0f);
-    const int t = (int)g - ib;
-    t_out = t;
-    if (MODE == 0) {
-        l = t >> 6;
-    } else if (MODE == 1) {
+__device__ __forceinline__ void axis_cell(const K1Params &P, int ib, const FaceCache &fc, int axis, float f, int &u, int &n, int &l, int &c,
+                                          uint32_t &q) {
+    const float g = floorf(__fmul_rn(f, P.inv_leaf));   // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
+    const int ti = (int)g;                               // v_cvt_i32_f32 (saturating; non-finite points are masked by the caller)
+    if (MODE == 1) {
         // leaf = (face mc - 1) + [f >= T(mc)] + [f >= T(mc + 1)], valid while the voxel lies between faces mc - 1/2 and mc + 3/2
-        miss |= (unsigned)(t - (fc.mc * 64 - 32)) >= 128u;
-        l = fc.mc - 1 + (f >= fc.tlo ? 1 : 0) + (f >= fc.thi ? 1 : 0);
+        u = ti - fc.cb;
+        n = (f >= fc.tlo ? 1 : 0) + (f >= fc.thi ? 1 : 0);
+        c = u - 64 * n;
     } else {
-        l = (int)floor(((double)f - P.mn0[axis]) / P.res);   // genOctreeKeyforPoint
+        const int t = ti - ib;
+        if (MODE == 0) l = t >> 6;
+        else l = (int)floor(((double)f - P.mn0[axis]) / P.res);   // genOctreeKeyforPoint
+        c = t - 64 * l + 2;
     }
-    c = t - 64 * l + 2;
-    // offset inside the voxel in 2^-22 voxel units; one rounding each (fma, product, convert)
-    q = (int)rintf(__fmul_rn(fmaf(-g, P.leaf, f), P.fix_scale));
+    // offset inside the voxel in fixed-point units, biased and rounded half up: (p - g * leaf) * scale + bias + 0.5, truncated
+    q = (uint32_t)(int)fmaf(fmaf(-g, P.leaf, f), P.fix_scale, P.q_round);
 }
 
 template <int MODE>
 __device__ __forceinline__ PointOut point_key(const K1Params &P, const FaceCache &f0, const FaceCache &f1, const FaceCache &f2, float fx, float fy,
-                                              float fz, bool present, bool &miss, int &t0, int &t1, int &t2, float &bn0, float &bn1, float &bn2,
-                                              float &bx0, float &bx1, float &bx2) {
+                                              float fz, bool present) {
     PointOut o;
-    bool good = present, pmiss = false;
-    int c0, c1, c2;
-    axis_cell<MODE>(P, P.ib0, f0, 0, fx, good, pmiss, t0, o.l0, c0, o.q0);
-    axis_cell<MODE>(P, P.ib1, f1, 1, fy, good, pmiss, t1, o.l1, c1, o.q1);
-    axis_cell<MODE>(P, P.ib2, f2, 2, fz, good, pmiss, t2, o.l2, c2, o.q2);
-    // Non-finite points are skipped as the octree does (addPointsFromInputCloud: isFinite) and stay out of
-    // the boxes: NaN is the neutral element of v_min/v_max.  So are points beyond 2^25 voxels.
-    const float nan = __uint_as_float(0x7fc00000u);
-    const float sx = good ? fx : nan, sy = good ? fy : nan, sz = good ? fz : nan;
-    bn0 = fminf(bn0, sx); bx0 = fmaxf(bx0, sx);
-    bn1 = fminf(bn1, sy); bx1 = fmaxf(bx1, sy);
-    bn2 = fminf(bn2, sz); bx2 = fmaxf(bx2, sz);
-    miss |= pmiss && good;
-    o.seen = good;
+    int c0, c1, c2, n0 = 0, n1 = 0, n2 = 0;
+    o.l0 = o.l1 = o.l2 = 0;
+    o.u0 = o.u1 = o.u2 = 0;
+    axis_cell<MODE>(P, P.ib0, f0, 0, fx, o.u0, n0, o.l0, c0, o.q0);
+    axis_cell<MODE>(P, P.ib1, f1, 1, fy, o.u1, n1, o.l1, c1, o.q1);
+    axis_cell<MODE>(P, P.ib2, f2, 2, fz, o.u2, n2, o.l2, c2, o.q2);
+    o.nn = (uint32_t)(n0 | (n1 << 2) | (n2 << 4));
+    // Non-finite points are skipped as the octree does (addPointsFromInputCloud: isFinite).  One test for
+    // the three coordinates: the sum is NaN or Inf iff one of them is (or they are beyond any sane range).
+    o.seen = present && __builtin_isfinite(fx + fy + fz);
     // memory safety: a cell outside the leaf grid must never become a record address
-    good &= (unsigned)c0 < (unsigned)GRID_DIM && (unsigned)c1 < (unsigned)GRID_DIM && (unsigned)c2 < (unsigned)GRID_DIM;
-    o.key = good ? (uint32_t)((c2 * GRID_DIM + c1) * GRID_DIM + c0) : KEY_EMPTY;
+    const uint32_t cm = max(max((uint32_t)c0, (uint32_t)c1), (uint32_t)c2);
+    o.key = (o.seen && cm < (uint32_t)GRID_DIM) ? (uint32_t)__umul24(__umul24((uint32_t)c2, GRID_DIM) + (uint32_t)c1, GRID_DIM) + (uint32_t)c0 : KEY_EMPTY;
     return o;
 }
 
-// r,g,b,tile bytes of one point into the run sums: two byte permutes instead of shifts and masks
-__device__ __forceinline__ void add_point(Run32 &r, const PointOut &o, uint32_t w) {
+// r,g,b,tile bytes of one point as addends of the run sums: byte permutes instead of shifts and masks
+struct PointAdd {
+    uint32_t cr;     // count << 16 | r
+    uint32_t gb;     // g << 16 | b
+    uint32_t tile;
+};
+__device__ __forceinline__ PointAdd point_add(uint32_t w) {
+    PointAdd a;
+    a.cr = (w & 0xffu) | 0x10000u;
+    a.gb = __builtin_amdgcn_perm(0u, w, 0x0c010c02u);   // bytes [b, 0, g, 0]
+    a.tile = w >> 24;
+    return a;
+}
+__device__ __forceinline__ void add_point(Run32 &r, const PointOut &o, const PointAdd &a) {
     r.qx += o.q0; r.qy += o.q1; r.qz += o.q2;
-    r.cr += (w & 0xffu) | 0x10000u;                                   // count << 16 | r
-    r.gb += __builtin_amdgcn_perm(0u, w, 0x0c010c02u);                // bytes [b, 0, g, 0] = g << 16 | b
-    r.tile |= w >> 24;
+    r.cr += a.cr; r.gb += a.gb; r.tile |= a.tile;
 }
 
 template <int MODE>
@@ -460,9 +476,16 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     FaceCache fc0, fc1, fc2;
     fc0.mc = fc1.mc = fc2.mc = -(1 << 24);   // covers nothing yet
     fc0.tlo = fc0.thi = fc1.tlo = fc1.thi = fc2.tlo = fc2.thi = 0.f;
+    fc0.cb = fc1.cb = fc2.cb = 1 << 30;
     int cl0 = 0, cl1 = 0, cl2 = 0;
     uint32_t cache_id = 0xffffffffu;
     bool cache_valid = false;
+    // the cached leaf relative to the cached faces, packed like PointOut::nn (0xff: not expressible, never equal)
+    uint32_t cnn = 0xffu;
+    auto update_cnn = [&]() {
+        const uint32_t r0 = (uint32_t)(cl0 - (fc0.mc - 1)), r1 = (uint32_t)(cl1 - (fc1.mc - 1)), r2 = (uint32_t)(cl2 - (fc2.mc - 1));
+        cnn = (cache_valid && r0 < 3u && r1 < 3u && r2 < 3u) ? (r0 | (r1 << 2) | (r2 << 4)) : 0xffu;
+    };
 
 #pragma unroll 1
     for (int off = 0; off < npts; off += WAVE_STEP) {
@@ -481,71 +504,116 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             continue;
         }
 
-        // ---- per point: cell, leaf lattice coordinates, fixed-point offsets (branch-free) ----
-        bool miss = false;
-        int t00, t01, t02, t10, t11, t12, t20, t21, t22, t30, t31, t32;
-        PointOut o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0, miss, t00, t01, t02, bn0, bn1, bn2, bx0, bx1, bx2);
-        PointOut o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1, miss, t10, t11, t12, bn0, bn1, bn2, bx0, bx1, bx2);
-        PointOut o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2, miss, t20, t21, t22, bn0, bn1, bn2, bx0, bx1, bx2);
-        PointOut o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3, miss, t30, t31, t32, bn0, bn1, bn2, bx0, bx1, bx2);
+        // ---- per point: cell, leaf, fixed-point offsets (branch-free) ----
+        PointOut o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0);
+        PointOut o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1);
+        PointOut o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2);
+        PointOut o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3);
 
-        if (MODE == 1 && __ballot(miss) != 0ull) {
-            // Some voxel of this step is not between the cached faces: move each axis' cache to the lowest
-            // face this step needs (thresholds come from the table the host computed), redo the step, and if
-            // lanes are still not covered (incoherent input) give up: the host reruns the exact variant.
-            const int big = 1 << 30;
-            int w0 = big, w1 = big, w2 = big;
-            if (o0.seen) { w0 = min(w0, t00); w1 = min(w1, t01); w2 = min(w2, t02); }
-            if (o1.seen) { w0 = min(w0, t10); w1 = min(w1, t11); w2 = min(w2, t12); }
-            if (o2.seen) { w0 = min(w0, t20); w1 = min(w1, t21); w2 = min(w2, t22); }
-            if (o3.seen) { w0 = min(w0, t30); w1 = min(w1, t31); w2 = min(w2, t32); }
-            for (int s = 32; s > 0; s >>= 1) {
-                w0 = min(w0, __shfl_xor(w0, s, 64)); w1 = min(w1, __shfl_xor(w1, s, 64)); w2 = min(w2, __shfl_xor(w2, s, 64));
-            }
-            bool off_table = false;
-            auto refill = [&](FaceCache &fc, int tmin, int fb, int axis) {
-                if (tmin == big) return;
-                const int m = (tmin + 32) >> 6;                 // nearest face of the lowest voxel
-                const unsigned i = (unsigned)(m - fb);
-                if (i + 1u >= (unsigned)FACES) { off_table = true; return; }
-                fc.mc = m;
-                fc.tlo = L.faces[axis * FACES + i];
-                fc.thi = L.faces[axis * FACES + i + 1];
+        // ---- box of the wave's range (input of the octree replay): skipped points stay out of it ----
+        if (__ballot(!(o0.seen && o1.seen && o2.seen && o3.seen)) == 0ull) {
+            bn0 = fminf(fminf(bn0, fminf(cx.x, cx.y)), fminf(cx.z, cx.w)); bx0 = fmaxf(fmaxf(bx0, fmaxf(cx.x, cx.y)), fmaxf(cx.z, cx.w));
+            bn1 = fminf(fminf(bn1, fminf(cy.x, cy.y)), fminf(cy.z, cy.w)); bx1 = fmaxf(fmaxf(bx1, fmaxf(cy.x, cy.y)), fmaxf(cy.z, cy.w));
+            bn2 = fminf(fminf(bn2, fminf(cz.x, cz.y)), fminf(cz.z, cz.w)); bx2 = fmaxf(fmaxf(bx2, fmaxf(cz.x, cz.y)), fmaxf(cz.z, cz.w));
+        } else {
+            // a ragged last step or non-finite points: NaN is the neutral element of v_min / v_max
+            const float nan = __uint_as_float(0x7fc00000u);
+            auto box = [&](bool seen, float fx, float fy, float fz) {
+                const float sx = seen ? fx : nan, sy = seen ? fy : nan, sz = seen ? fz : nan;
+                bn0 = fminf(bn0, sx); bx0 = fmaxf(bx0, sx);
+                bn1 = fminf(bn1, sy); bx1 = fmaxf(bx1, sy);
+                bn2 = fminf(bn2, sz); bx2 = fmaxf(bx2, sz);
             };
-            refill(fc0, __builtin_amdgcn_readfirstlane(w0), P.fb0, 0);
-            refill(fc1, __builtin_amdgcn_readfirstlane(w1), P.fb1, 1);
-            refill(fc2, __builtin_amdgcn_readfirstlane(w2), P.fb2, 2);
-            miss = false;
-            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;   // the boxes already hold this step
-            o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0, miss, t00, t01, t02, d0, d1, d2, d3, d4, d5);
-            o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1, miss, t10, t11, t12, d0, d1, d2, d3, d4, d5);
-            o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2, miss, t20, t21, t22, d0, d1, d2, d3, d4, d5);
-            o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3, miss, t30, t31, t32, d0, d1, d2, d3, d4, d5);
-            if (off_table || __ballot(miss) != 0ull) {
-                err |= ERR_FACE_TABLE;
-                o0.key = o1.key = o2.key = o3.key = KEY_EMPTY;
+            box(o0.seen, cx.x, cy.x, cz.x); box(o1.seen, cx.y, cy.y, cz.y); box(o2.seen, cx.z, cy.z, cz.z); box(o3.seen, cx.w, cy.w, cz.w);
+        }
+
+        if (MODE == 1) {
+            // Are all voxels of this step between the cached faces?  u - 34 = voxel - (64 mc - 32) must lie in [0, 128).
+            // Cheap test on the lane's extremes first; points that do not count (absent, non-finite) can only
+            // raise a false alarm, which the exact test below sorts out.
+            auto spread = [](int a, int b, int c, int d) {
+                const int lo = min(min(a, b), min(c, d)), hi = max(max(a, b), max(c, d));
+                return (uint32_t)(lo - 34) | (uint32_t)(hi - 34);
+            };
+            const uint32_t out = spread(o0.u0, o1.u0, o2.u0, o3.u0) | spread(o0.u1, o1.u1, o2.u1, o3.u1) | spread(o0.u2, o1.u2, o2.u2, o3.u2);
+            if (__ballot(out >= 128u) != 0ull) {
+                auto outside = [](const PointOut &o) {
+                    return o.seen && (((uint32_t)(o.u0 - 34) | (uint32_t)(o.u1 - 34) | (uint32_t)(o.u2 - 34)) >= 128u);
+                };
+                if (__ballot(outside(o0) || outside(o1) || outside(o2) || outside(o3)) != 0ull) {
+                    // Move each axis' cache to the lowest face this step needs (thresholds come from the table
+                    // the host computed), redo the step, and if lanes are still not covered (incoherent input)
+                    // give up: the host reruns the exact variant.
+                    const int big = 1 << 30;
+                    int w0 = big, w1 = big, w2 = big;   // lowest voxel index per axis, t = u + cb - ib
+                    if (o0.seen) { w0 = min(w0, o0.u0); w1 = min(w1, o0.u1); w2 = min(w2, o0.u2); }
+                    if (o1.seen) { w0 = min(w0, o1.u0); w1 = min(w1, o1.u1); w2 = min(w2, o1.u2); }
+                    if (o2.seen) { w0 = min(w0, o2.u0); w1 = min(w1, o2.u1); w2 = min(w2, o2.u2); }
+                    if (o3.seen) { w0 = min(w0, o3.u0); w1 = min(w1, o3.u1); w2 = min(w2, o3.u2); }
+                    for (int sft = 32; sft > 0; sft >>= 1) {
+                        w0 = min(w0, __shfl_xor(w0, sft, 64)); w1 = min(w1, __shfl_xor(w1, sft, 64)); w2 = min(w2, __shfl_xor(w2, sft, 64));
+                    }
+                    bool off_table = false;
+                    auto refill = [&](FaceCache &fc, int umin, int ib, int fb, int axis) {
+                        if (umin == big) return;
+                        const int tmin = umin + fc.cb - ib;
+                        const int m = (tmin + 32) >> 6;                 // nearest face of the lowest voxel
+                        const unsigned i = (unsigned)(m - fb);
+                        if (i + 1u >= (unsigned)FACES) { off_table = true; return; }
+                        fc.mc = m;
+                        fc.tlo = L.faces[axis * FACES + i];
+                        fc.thi = L.faces[axis * FACES + i + 1];
+                        fc.cb = ib + 64 * (m - 1) - 2;
+                    };
+                    refill(fc0, __builtin_amdgcn_readfirstlane(w0), P.ib0, P.fb0, 0);
+                    refill(fc1, __builtin_amdgcn_readfirstlane(w1), P.ib1, P.fb1, 1);
+                    refill(fc2, __builtin_amdgcn_readfirstlane(w2), P.ib2, P.fb2, 2);
+                    update_cnn();
+                    o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0);
+                    o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1);
+                    o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2);
+                    o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3);
+                    if (off_table || __ballot(outside(o0) || outside(o1) || outside(o2) || outside(o3)) != 0ull) {
+                        err |= ERR_FACE_TABLE;
+                        o0.key = o1.key = o2.key = o3.key = KEY_EMPTY;
+                    }
+                }
             }
         }
 
         if (P.ablate & 2u) {   // diagnostics: loads + per-point arithmetic only
-            bx0 = fmaxf(bx0, __uint_as_float((o0.key ^ o1.key ^ o2.key ^ o3.key) + (uint32_t)(o0.q0 + o1.q1 + o2.q2 + o3.q0 + o0.l0 + o1.l1 + o2.l2)));
+            bx0 = fmaxf(bx0, __uint_as_float((o0.key ^ o1.key ^ o2.key ^ o3.key) + (o0.q0 + o1.q1 + o2.q2 + o3.q0 + o0.nn + o1.nn + o2.nn + o3.nn) +
+                                              (uint32_t)(o0.l0 + o1.l1 + o2.l2)));
             cx = nx; cy = ny; cz = nz; cw = nw;
             continue;
         }
 
         // ---- leaf ids ----
         {
-            int mism = 0;
-            mism |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
-            mism |= o1.key != KEY_EMPTY ? (o1.l0 ^ cl0) | (o1.l1 ^ cl1) | (o1.l2 ^ cl2) : 0;
-            mism |= o2.key != KEY_EMPTY ? (o2.l0 ^ cl0) | (o2.l1 ^ cl1) | (o2.l2 ^ cl2) : 0;
-            mism |= o3.key != KEY_EMPTY ? (o3.l0 ^ cl0) | (o3.l1 ^ cl1) | (o3.l2 ^ cl2) : 0;
-            if (cache_valid && __ballot(mism != 0) == 0ull) {
+            bool mism;
+            if (MODE == 1) {
+                mism = (o0.key != KEY_EMPTY && o0.nn != cnn) || (o1.key != KEY_EMPTY && o1.nn != cnn) || (o2.key != KEY_EMPTY && o2.nn != cnn) ||
+                       (o3.key != KEY_EMPTY && o3.nn != cnn);
+            } else {
+                int mm = 0;
+                mm |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
+                mm |= o1.key != KEY_EMPTY ? (o1.l0 ^ cl0) | (o1.l1 ^ cl1) | (o1.l2 ^ cl2) : 0;
+                mm |= o2.key != KEY_EMPTY ? (o2.l0 ^ cl0) | (o2.l1 ^ cl1) | (o2.l2 ^ cl2) : 0;
+                mm |= o3.key != KEY_EMPTY ? (o3.l0 ^ cl0) | (o3.l1 ^ cl1) | (o3.l2 ^ cl2) : 0;
+                mism = mm != 0;
+            }
+            if (cache_valid && __ballot(mism) == 0ull) {
                 // the whole step lies in the cached leaf (the common case); KEY_EMPTY stays all ones
                 const uint32_t hi_bits = cache_id << CELL_BITS;
                 o0.key |= hi_bits; o1.key |= hi_bits; o2.key |= hi_bits; o3.key |= hi_bits;
             } else {
                 // general case: resolve the distinct leaves of this step one at a time
+                if (MODE == 1) {
+                    auto leaf_of = [&](PointOut &o) {
+                        o.l0 = fc0.mc - 1 + (int)(o.nn & 3u); o.l1 = fc1.mc - 1 + (int)((o.nn >> 2) & 3u); o.l2 = fc2.mc - 1 + (int)(o.nn >> 4);
+                    };
+                    leaf_of(o0); leaf_of(o1); leaf_of(o2); leaf_of(o3);
+                }
                 unsigned pend = (o0.key != KEY_EMPTY ? 1u : 0u) | (o1.key != KEY_EMPTY ? 2u : 0u) | (o2.key != KEY_EMPTY ? 4u : 0u) |
                                 (o3.key != KEY_EMPTY ? 8u : 0u);
                 for (;;) {
@@ -571,51 +639,124 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     if ((pend & 4u) && o2.l0 == s0 && o2.l1 == s1 && o2.l2 == s2) { pend &= ~4u; o2.key = lost ? KEY_EMPTY : (o2.key | hi_bits); }
                     if ((pend & 8u) && o3.l0 == s0 && o3.l1 == s1 && o3.l2 == s2) { pend &= ~8u; o3.key = lost ? KEY_EMPTY : (o3.key | hi_bits); }
                 }
+                update_cnn();
             }
         }
 
-        // ---- runs of this lane; lanes whose 4 points share one voxel take part in the wave merge ----
-        const int ri1 = o1.key != o0.key ? 1 : 0;
-        const int ri2 = ri1 + (o2.key != o1.key ? 1 : 0);
-        const int ri3 = ri2 + (o3.key != o2.key ? 1 : 0);
-        const int nruns = ri3 + 1;
-        const bool single = nruns == 1 && o0.key != KEY_EMPTY;
-        Run32 v;
-        v.key = single ? o0.key : KEY_EMPTY;
-        v.qx = v.qy = v.qz = 0;
-        v.cr = v.gb = v.tile = 0;
-        add_point(v, o0, cw.x); add_point(v, o1, cw.y); add_point(v, o2, cw.z); add_point(v, o3, cw.w);
-        const int smask = single ? -1 : 0;   // lanes with several voxels contribute nothing to the merge
-        v.qx &= smask; v.qy &= smask; v.qz &= smask;
-        v.cr &= (uint32_t)smask; v.gb &= (uint32_t)smask; v.tile &= (uint32_t)smask;
-        // segmented inclusive scan over chains of consecutive single lanes with equal keys; chains are
-        // cut every 8 lanes so that three DPP steps (1, 2, 4) cover them completely
-        const int prev_key = dpp_shr<1>((int)v.key);
-        int flag = (!single || (lane & 7) == 0 || (uint32_t)prev_key != v.key) ? 1 : 0;
-        scan_step<1>(v, flag);
-        scan_step<2>(v, flag);
-        scan_step<4>(v, flag);
-        // a chain ends where the next lane does not continue it
-        const int next_key = dpp_shl<1>((int)v.key);
-        const bool chain_end = single && ((lane & 7) == 7 || (uint32_t)next_key != v.key);
+        // ---- runs inside the lane ----
+        // A lane's 4 consecutive points form 1 run (the usual case) or a head run, a tail run and up to two
+        // runs in between.  The tail (the whole lane if it is one run) takes part in a segmented scan over
+        // lanes; the head is handed to the previous lane, whose chain it ends; a run in between is complete
+        // as it is.  So a run that spans several lanes is inserted into the workgroup table once, by the lane
+        // where its chain ends, and most steps need one table insert per lane at most (LDS atomics are the
+        // scarcest resource of this kernel).
+        const uint32_t k0 = o0.key, k1 = o1.key, k2 = o2.key, k3 = o3.key;
+        const bool e1 = k1 == k0, e2 = k2 == k1, e3 = k3 == k2;
+        const int nb = (e1 ? 0 : 1) + (e2 ? 0 : 1) + (e3 ? 0 : 1);   // boundaries inside the lane
+        const bool single = nb == 0, multi = nb != 0;
+        const PointAdd a0 = point_add(cw.x), a1 = point_add(cw.y), a2 = point_add(cw.z), a3 = point_add(cw.w);
+        Run32 all;   // the four points together
+        all.key = k3;
+        all.qx = (o0.q0 + o1.q0) + (o2.q0 + o3.q0);
+        all.qy = (o0.q1 + o1.q1) + (o2.q1 + o3.q1);
+        all.qz = (o0.q2 + o1.q2) + (o2.q2 + o3.q2);
+        all.cr = (a0.cr + a1.cr) + (a2.cr + a3.cr);
+        all.gb = (a0.gb + a1.gb) + (a2.gb + a3.gb);
+        all.tile = (a0.tile | a1.tile) | (a2.tile | a3.tile);
+        Run32 H;     // head: the points before the first boundary
+        {
+            const uint32_t m1 = e1 ? ~0u : 0u, m2 = (e1 && e2) ? ~0u : 0u;
+            H.key = k0;
+            H.qx = o0.q0 + (o1.q0 & m1) + (o2.q0 & m2);
+            H.qy = o0.q1 + (o1.q1 & m1) + (o2.q1 & m2);
+            H.qz = o0.q2 + (o1.q2 & m1) + (o2.q2 & m2);
+            H.cr = a0.cr + (a1.cr & m1) + (a2.cr & m2);
+            H.gb = a0.gb + (a1.gb & m1) + (a2.gb & m2);
+            H.tile = a0.tile | (a1.tile & m1) | (a2.tile & m2);
+        }
+        Run32 T;     // tail: the points after the last boundary
+        {
+            const uint32_t n2 = e3 ? ~0u : 0u, n1 = (e3 && e2) ? ~0u : 0u;
+            T.key = k3;
+            T.qx = o3.q0 + (o2.q0 & n2) + (o1.q0 & n1);
+            T.qy = o3.q1 + (o2.q1 & n2) + (o1.q1 & n1);
+            T.qz = o3.q2 + (o2.q2 & n2) + (o1.q2 & n1);
+            T.cr = a3.cr + (a2.cr & n2) + (a1.cr & n1);
+            T.gb = a3.gb + (a2.gb & n2) + (a1.gb & n1);
+            T.tile = a3.tile | (a2.tile & n2) | (a1.tile & n1);
+        }
+        Run32 X;     // what the lane contributes to the scan
+        X.key = k3;
+        X.qx = single ? all.qx : T.qx; X.qy = single ? all.qy : T.qy; X.qz = single ? all.qz : T.qz;
+        X.cr = single ? all.cr : T.cr; X.gb = single ? all.gb : T.gb; X.tile = single ? all.tile : T.tile;
+        // ---- segmented inclusive scan over chains of lanes; chains are cut every 8 lanes so that three
+        // DPP steps (1, 2, 4) cover them completely
+        const uint32_t prev_xkey = (uint32_t)dpp_shr<1>((int)k3);   // 0 in the first lane of a row of 16
+        const int flag0 = (single && (lane & 7) != 0 && prev_xkey == k0) ? 0 : 1;   // 1: the lane starts a chain
+        int flag = flag0;
+        scan_step<1>(X, flag);
+        scan_step<2>(X, flag);
+        scan_step<4>(X, flag);
+        // ---- where chains end; the head of the next lane, if it continues this chain ----
+        // (cross-lane reads first, into plain variables: inside a short-circuit they would run with part
+        // of the wave switched off and read zeros from those lanes)
+        const bool row_first = (lane & 15) == 0, row_last = (lane & 15) == 15;
+        const int next_flag0 = dpp_shl<1>(flag0), next_multi = dpp_shl<1>(multi ? 1 : 0);
+        const uint32_t next_k0 = (uint32_t)dpp_shl<1>((int)k0);
+        const bool tail_final = row_last | (next_flag0 != 0);
+        const bool take = !row_last & (next_multi != 0) & (next_k0 == k3);
+        {
+            const int tm = take ? -1 : 0;
+            X.qx += (uint32_t)(dpp_shl<1>((int)H.qx) & tm);
+            X.qy += (uint32_t)(dpp_shl<1>((int)H.qy) & tm);
+            X.qz += (uint32_t)(dpp_shl<1>((int)H.qz) & tm);
+            X.cr += (uint32_t)(dpp_shl<1>((int)H.cr) & tm);
+            X.gb += (uint32_t)(dpp_shl<1>((int)H.gb) & tm);
+            X.tile |= (uint32_t)(dpp_shl<1>((int)H.tile) & tm);
+        }
+        // this lane's head is taken by the previous lane under exactly the condition `take` has there
+        const bool head_taken = multi & !row_first & (prev_xkey == k0);
 
-        // ---- insert rounds: round k carries run k of every lane (round 0: chain ends of merged lanes) ----
+        // ---- table inserts ----
+        // what a lane has to insert, in this order: its chain (if it ends here), its head (if nobody took
+        // it), the run(s) between head and tail.  Round 0 takes the first of them, which is all there is in
+        // most steps of a scan-ordered cloud.
         if (!(P.ablate & 4u)) {
-            if (chain_end) lds_insert(L, W, P.list_cap, P.q_bias, v);
-            if (__ballot(!single && nruns > 1) != 0ull) {
+            const bool have_t = tail_final & (k3 != KEY_EMPTY);
+            const bool have_h = multi & !head_taken & (k0 != KEY_EMPTY);
+            Run32 M1, M2;   // nb == 2: one run in between (everything but head and tail); nb == 3: points 1 and 2
+            M1.key = M2.key = KEY_EMPTY;
+            M1.qx = M1.qy = M1.qz = M1.cr = M1.gb = M1.tile = 0;
+            M2 = M1;
+            if (__ballot(nb >= 2) != 0ull) {
+                const bool three = nb == 3;
+                const uint32_t sm = three ? ~0u : 0u;   // nb == 3: point 2 is a run of its own
+                M1.key = nb >= 2 ? (e1 ? k2 : k1) : KEY_EMPTY;
+                M1.qx = all.qx - H.qx - T.qx - (o2.q0 & sm);
+                M1.qy = all.qy - H.qy - T.qy - (o2.q1 & sm);
+                M1.qz = all.qz - H.qz - T.qz - (o2.q2 & sm);
+                M1.cr = all.cr - H.cr - T.cr - (a2.cr & sm);
+                M1.gb = all.gb - H.gb - T.gb - (a2.gb & sm);
+                M1.tile = three ? a1.tile : (e1 ? a2.tile : (a1.tile | (e2 ? a2.tile : 0u)));
+                M2.key = three ? k2 : KEY_EMPTY;
+                M2.qx = o2.q0; M2.qy = o2.q1; M2.qz = o2.q2; M2.cr = a2.cr; M2.gb = a2.gb; M2.tile = a2.tile;
+            }
+            const bool have_m1 = M1.key != KEY_EMPTY, have_m2 = M2.key != KEY_EMPTY;
+            const int i_h = have_t ? 1 : 0, i_m1 = i_h + (have_h ? 1 : 0), i_m2 = i_m1 + (have_m1 ? 1 : 0);
+            const int n_items = i_m2 + (have_m2 ? 1 : 0);
 #pragma unroll 1
-                for (int k = 0; k < 4; k++) {
-                    if (__ballot(!single && nruns > k) == 0ull) break;
-                    Run32 r;
-                    r.key = KEY_EMPTY;
-                    r.qx = r.qy = r.qz = 0;
-                    r.cr = r.gb = r.tile = 0;
-                    if (k == 0) { r.key = o0.key; add_point(r, o0, cw.x); }
-                    if (k == ri1) { r.key = o1.key; add_point(r, o1, cw.y); }
-                    if (k == ri2) { r.key = o2.key; add_point(r, o2, cw.z); }
-                    if (k == ri3) { r.key = o3.key; add_point(r, o3, cw.w); }
-                    if (!single && k < nruns && r.key != KEY_EMPTY) lds_insert(L, W, P.list_cap, P.q_bias, r);
-                }
+            for (int round = 0; round < 4; round++) {
+                if (round > 0 && __ballot(n_items > round) == 0ull) break;
+                const bool s_t = have_t & (round == 0), s_h = have_h & (round == i_h), s_m1 = have_m1 & (round == i_m1), s_m2 = have_m2 & (round == i_m2);
+                Run32 r;
+                r.key = s_t ? k3 : s_h ? k0 : s_m1 ? M1.key : s_m2 ? M2.key : KEY_EMPTY;
+                r.qx = s_t ? X.qx : s_h ? H.qx : s_m1 ? M1.qx : M2.qx;
+                r.qy = s_t ? X.qy : s_h ? H.qy : s_m1 ? M1.qy : M2.qy;
+                r.qz = s_t ? X.qz : s_h ? H.qz : s_m1 ? M1.qz : M2.qz;
+                r.cr = s_t ? X.cr : s_h ? H.cr : s_m1 ? M1.cr : M2.cr;
+                r.gb = s_t ? X.gb : s_h ? H.gb : s_m1 ? M1.gb : M2.gb;
+                r.tile = s_t ? X.tile : s_h ? H.tile : s_m1 ? M1.tile : M2.tile;
+                lds_insert(L, W, P.list_cap, P.q_bias, r, r.key != KEY_EMPTY);
             }
         }
         cx = nx; cy = ny; cz = nz; cw = nw;
@@ -1353,7 +1494,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         K.fb0 = P.face_base[0]; K.fb1 = P.face_base[1]; K.fb2 = P.face_base[2];
         K.leaf_mask = P.leaf_mask; K.list_cap = P.list_cap; K.ablate = P.ablate;
         K.q_bias = wide ? Q_BIAS_WIDE : Q_BIAS;
-        K.g_check = wide ? INFINITY : G_CHECK;
+        K.q_round = (float)K.q_bias + 0.5f;
+        K.g_check = wide ? G_CHECK_WIDE : G_CHECK;
         K.mn0[0] = P.mn0[0]; K.mn0[1] = P.mn0[1]; K.mn0[2] = P.mn0[2];
         K.res = P.res;
         if (mode == 0) {
@@ -1448,6 +1590,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             // the touched records were cleaned above; change what was too small and run again
             if (err & ERR_FACE_TABLE) mode = 2;   // points beyond the threshold table: per-point f64 variant
             if (err & ERR_FIXED_RANGE) {
+                if (wide) {
+                    cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: coordinates beyond 2^25 voxels from the origin");
+                    return nullptr;
+                }
                 wide = true;
                 P.fix_scale = FIX_ONE_WIDE_F / cellsize;
             }
