@@ -75,6 +75,7 @@ constexpr int CELLS = GRID_DIM * GRID_DIM * GRID_DIM;   // 314432 < 2^19
 constexpr int CELL_BITS = 19;
 constexpr int BITWORDS = CELLS / 32;            // 9826 occupancy words per leaf grid (CELLS is a multiple of 32)
 constexpr uint32_t KEY_EMPTY = 0xffffffffu;
+constexpr int LOCAL_LEAVES = 64;               // leaves a workgroup can name locally (keys carry the local slot, the flush translates)
 // the finalize pass works on slices of a leaf's occupancy bitmap
 constexpr int RANK_THREADS = 256;
 constexpr int RANK_SEGS = 8;
@@ -103,6 +104,7 @@ enum : uint32_t {
     ERR_FACE_TABLE = 32,     // a point lies beyond the threshold table (host reruns the exact variant)
     ERR_CELL_RANGE = 64,
     ERR_LIST_FULL = 128,
+    ERR_LOCAL_LEAVES = 512,  // a workgroup met more leaves than its local leaf table holds: host reruns with global leaf ids in the hot loop
     ERR_FIXED_RANGE = 256,   // coordinates beyond 4e6 voxels: host reruns with the wide fixed-point scale
 };
 
@@ -284,6 +286,8 @@ struct LdsTable {
     float faces[3 * FACES];
     uint32_t htag[64], hcnt[64];  // first touches per bitmap slice of this workgroup (slice + 1, count)
     uint32_t nfresh, fresh_base;
+    unsigned long long leaf_tab[LOCAL_LEAVES];   // packed leaf coordinates, 0 = free; position = local leaf slot
+    uint32_t leaf_gid[LOCAL_LEAVES];             // global leaf id of each slot (filled before the flush)
 };
 
 // The slim parameter block of K1 (kernel arguments live in SGPRs; K1 is short of them).
@@ -293,6 +297,7 @@ struct K1Params {
     int ib0, ib1, ib2;
     int fb0, fb1, fb2;
     uint32_t leaf_mask, list_cap, ablate;
+    uint32_t local_leaves;   // 1: keys carry workgroup-local leaf slots (no global memory access in the hot loop)
     uint32_t q_bias;    // per-point bias of the offset sums
     float q_round;      // q_bias + 0.5 (the offset is biased and rounded by one fma, then truncated)
     float g_check;      // |coordinate * inv_leaf| a wave may see at this scale (inf: no limit)
@@ -304,7 +309,22 @@ __device__ __forceinline__ unsigned long long u64_of(uint32_t lo, uint32_t hi) {
 
 // Add one run to the workgroup table.  All in-wave sums are 32-bit (<= 256 points), so the four
 // packed 64-bit addends are assembled from 32-bit halves.
-__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32_t list_cap, uint32_t q_bias, const Run32 &r, bool active) {
+// One lane: slot of leaf k in the workgroup's local leaf table, inserting it if new; 0xffffffff when the table is full.
+__device__ __forceinline__ uint32_t local_leaf_slot(LdsTable &L, unsigned long long k) {
+    uint32_t pos = (((uint32_t)k ^ (uint32_t)(k >> 21) ^ (uint32_t)(k >> 42)) * 0x9E3779B1u) >> 26;   // LOCAL_LEAVES = 2^6
+    for (int probe = 0; probe < LOCAL_LEAVES; probe++) {
+        const unsigned long long cur = L.leaf_tab[pos];
+        if (cur == k) return pos;
+        if (cur == 0ull) {
+            const unsigned long long old = atomicCAS(&L.leaf_tab[pos], 0ull, k);
+            if (old == 0ull || old == k) return pos;
+        }
+        pos = (pos + 1) & (LOCAL_LEAVES - 1);
+    }
+    return 0xffffffffu;
+}
+
+__device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const K1Params &P, const Run32 &r, bool active) {
     // Called by the whole wave (active = this lane has something to insert).  The slot search is a loop
     // of its own, so that the adds are issued once per call however many probes the unluckiest lane needs:
     // LDS atomics are the scarcest resource of this kernel.
@@ -333,8 +353,14 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, uint32
     }
     if (active && pending) {   // table saturated (incoherent input): straight to the global records
         const uint32_t cnt = r.cr >> 16;
-        const long long bias = (long long)cnt * q_bias;
-        global_insert_lane(W, list_cap, r.key, (long long)r.qx - bias, (long long)r.qy - bias, (long long)r.qz - bias, u64_of(r.cr & 0xffffu, cnt),
+        const long long bias = (long long)cnt * P.q_bias;
+        uint32_t gkey = r.key;
+        if (P.local_leaves) {
+            const uint32_t gid = leaf_lookup(W, P.leaf_mask, L.leaf_tab[r.key >> CELL_BITS]);
+            gkey = (gid << CELL_BITS) | (r.key & ((1u << CELL_BITS) - 1));
+            if (gid == 0xffffffffu) return;   // ERR_LEAVES is set: the pass is discarded
+        }
+        global_insert_lane(W, P.list_cap, gkey, (long long)r.qx - bias, (long long)r.qy - bias, (long long)r.qz - bias, u64_of(r.cr & 0xffffu, cnt),
                            u64_of(r.gb & 0xffffu, r.gb >> 16), r.tile);
     }
 }
@@ -469,6 +495,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         for (int i = threadIdx.x; i < 3 * FACES; i += K1_THREADS) L.faces[i] = W.faces[i];
     }
     if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
+    if (threadIdx.x < LOCAL_LEAVES) { L.leaf_tab[threadIdx.x] = 0ull; L.leaf_gid[threadIdx.x] = 0xffffffffu; }
     if (threadIdx.x == 0) L.nfresh = 0;
     __syncthreads();
 
@@ -589,7 +616,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
 
         // ---- leaf ids ----
-        {
+        if (!(P.ablate & 64u)) {
             bool mism;
             if (MODE == 1) {
                 mism = (o0.key != KEY_EMPTY && o0.nn != cnn) || (o1.key != KEY_EMPTY && o1.nn != cnn) || (o2.key != KEY_EMPTY && o2.nn != cnn) ||
@@ -627,8 +654,9 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     const int s0 = __builtin_amdgcn_readlane(m0, src), s1 = __builtin_amdgcn_readlane(m1, src), s2 = __builtin_amdgcn_readlane(m2, src);
                     if (!(cache_valid && s0 == cl0 && s1 == cl1 && s2 == cl2)) {
                         uint32_t found = 0;
-                        if (lane == src) found = leaf_lookup(W, P.leaf_mask, pack_leaf(s0, s1, s2));
+                        if (lane == src) found = P.local_leaves ? local_leaf_slot(L, pack_leaf(s0, s1, s2)) : leaf_lookup(W, P.leaf_mask, pack_leaf(s0, s1, s2));
                         cache_id = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
+                        if (P.local_leaves && cache_id == 0xffffffffu) err |= ERR_LOCAL_LEAVES;
                         cl0 = s0; cl1 = s1; cl2 = s2;
                         cache_valid = true;
                     }
@@ -694,9 +722,11 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         const uint32_t prev_xkey = (uint32_t)dpp_shr<1>((int)k3);   // 0 in the first lane of a row of 16
         const int flag0 = (single && (lane & 7) != 0 && prev_xkey == k0) ? 0 : 1;   // 1: the lane starts a chain
         int flag = flag0;
-        scan_step<1>(X, flag);
-        scan_step<2>(X, flag);
-        scan_step<4>(X, flag);
+        if (!(P.ablate & 16u)) {
+            scan_step<1>(X, flag);
+            scan_step<2>(X, flag);
+            scan_step<4>(X, flag);
+        }
         // ---- where chains end; the head of the next lane, if it continues this chain ----
         // (cross-lane reads first, into plain variables: inside a short-circuit they would run with part
         // of the wave switched off and read zeros from those lanes)
@@ -705,7 +735,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         const uint32_t next_k0 = (uint32_t)dpp_shl<1>((int)k0);
         const bool tail_final = row_last | (next_flag0 != 0);
         const bool take = !row_last & (next_multi != 0) & (next_k0 == k3);
-        {
+        if (!(P.ablate & 32u)) {
             const int tm = take ? -1 : 0;
             X.qx += (uint32_t)(dpp_shl<1>((int)H.qx) & tm);
             X.qy += (uint32_t)(dpp_shl<1>((int)H.qy) & tm);
@@ -756,7 +786,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                 r.cr = s_t ? X.cr : s_h ? H.cr : s_m1 ? M1.cr : M2.cr;
                 r.gb = s_t ? X.gb : s_h ? H.gb : s_m1 ? M1.gb : M2.gb;
                 r.tile = s_t ? X.tile : s_h ? H.tile : s_m1 ? M1.tile : M2.tile;
-                lds_insert(L, W, P.list_cap, P.q_bias, r, r.key != KEY_EMPTY);
+                lds_insert(L, W, P, r, r.key != KEY_EMPTY);
             }
         }
         cx = nx; cy = ny; cz = nz; cw = nw;
@@ -787,6 +817,14 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     // All adds of a lane are issued before the first result is looked at, so that their round
     // trips overlap (this is the serial tail of the kernel: nothing else is in flight any more).
     __syncthreads();
+    if (P.local_leaves) {
+        // local leaf slots -> global leaf ids (grids), one lookup per leaf and workgroup
+        if (threadIdx.x < LOCAL_LEAVES) {
+            const unsigned long long lk = L.leaf_tab[threadIdx.x];
+            if (lk != 0ull) L.leaf_gid[threadIdx.x] = leaf_lookup(W, P.leaf_mask, lk);
+        }
+        __syncthreads();
+    }
     const int sub = threadIdx.x & 7;
     constexpr int FLUSH_ITERS = LTAB / (K1_THREADS / 8);
     uint32_t fkey[FLUSH_ITERS];
@@ -796,6 +834,10 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         const int e = (threadIdx.x >> 3) + it * (K1_THREADS / 8);
         uint32_t k = L.key[e];
         if (P.ablate & 8u) k = KEY_EMPTY;
+        if (P.local_leaves && k != KEY_EMPTY) {
+            const uint32_t gid = L.leaf_gid[k >> CELL_BITS];
+            k = gid == 0xffffffffu ? KEY_EMPTY : ((gid << CELL_BITS) | (k & ((1u << CELL_BITS) - 1)));
+        }
         fkey[it] = k;
         fold[it] = ~0ull;
         if (k == KEY_EMPTY) continue;
@@ -1437,6 +1479,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     P.inv_leaf = 1.0f / cellsize;
     P.fix_scale = FIX_ONE_F / cellsize;
     bool wide = false;
+    bool local_leaves = true;   // leaf ids resolved per workgroup at flush time; off after ERR_LOCAL_LEAVES
     P.leaf_d = (double)cellsize;
     const float octree_cellsize = (8 * 8) * cellsize;   // reference src/cwipc_filters.cpp:113-114
     P.res = (double)octree_cellsize;
@@ -1467,7 +1510,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
 
     uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 64;   // 64 grids = 1.3 GB; grown x4 when a cloud has more leaves
     int mode = leaf_split ? 1 : 0;
-    for (int attempt = 0; attempt < 9; attempt++) {
+    for (int attempt = 0; attempt < 10; attempt++) {
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
@@ -1494,6 +1537,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         K.fb0 = P.face_base[0]; K.fb1 = P.face_base[1]; K.fb2 = P.face_base[2];
         K.leaf_mask = P.leaf_mask; K.list_cap = P.list_cap; K.ablate = P.ablate;
         K.q_bias = wide ? Q_BIAS_WIDE : Q_BIAS;
+        K.local_leaves = local_leaves ? 1u : 0u;
         K.q_round = (float)K.q_bias + 0.5f;
         K.g_check = wide ? G_CHECK_WIDE : G_CHECK;
         K.mn0[0] = P.mn0[0]; K.mn0[1] = P.mn0[1]; K.mn0[2] = P.mn0[2];
@@ -1585,8 +1629,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (error_code) *error_code = (int)err;
         if (!ok) { hip_failed(hipGetLastError(), "voxel emit", __FILE__, __LINE__); return nullptr; }
 
-        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE | ERR_LIST_FULL;
-        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE)) && !(err & ~retryable)) {
+        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE | ERR_LOCAL_LEAVES | ERR_LIST_FULL;
+        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE | ERR_LOCAL_LEAVES)) && !(err & ~retryable)) {
+            if (err & ERR_LOCAL_LEAVES) local_leaves = false;   // a workgroup spans more than 64 leaves: global ids in the hot loop
             // the touched records were cleaned above; change what was too small and run again
             if (err & ERR_FACE_TABLE) mode = 2;   // points beyond the threshold table: per-point f64 variant
             if (err & ERR_FIXED_RANGE) {

@@ -346,6 +346,19 @@ def test_downsample_random_volume(gpu, oracle):
         check_downsample(gpu, oracle, pts, 0.0, cell)
 
 
+def test_downsample_many_leaves_in_random_order(gpu, oracle):
+    """Incoherent input over ~125 octree leaves: every workgroup meets more leaves than its local leaf table
+    names (second pass with global leaf ids), and more than the initial number of leaf grids (workspace regrown)."""
+    rng = np.random.default_rng(33)
+    n = 150000
+    pts = oracle.empty(n)
+    pts['x'], pts['y'], pts['z'] = rng.random(n) * 3.0 - 1.5, rng.random(n) * 3.0, rng.random(n) * 3.0 - 1.0
+    pts['r'], pts['g'], pts['b'] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n)
+    pts['tile'] = 1 << rng.integers(0, 8, n)
+    check_downsample(gpu, oracle, pts, 0.0, 0.01)
+    check_downsample(gpu, oracle, pts, 0.0, -0.01)
+
+
 def test_downsample_single_point_and_duplicates(gpu, oracle):
     pts = oracle.empty(1)
     pts['x'], pts['y'], pts['z'], pts['r'], pts['tile'] = 0.5, -0.25, 3.0, 200, 4
