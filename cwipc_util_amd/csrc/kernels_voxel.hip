@@ -288,6 +288,7 @@ struct LdsTable {
     uint32_t nfresh, fresh_base;
     unsigned long long leaf_tab[LOCAL_LEAVES];   // packed leaf coordinates, 0 = free; position = local leaf slot
     uint32_t leaf_gid[LOCAL_LEAVES];             // global leaf id of each slot (filled before the flush)
+    uint32_t nn_leaf[K1_WAVES][64];              // per wave: leaf (slot or id) of each leaf position relative to the cached faces, ~0 = not looked up yet
 };
 
 // The slim parameter block of K1 (kernel arguments live in SGPRs; K1 is short of them).
@@ -496,6 +497,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     }
     if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
     if (threadIdx.x < LOCAL_LEAVES) { L.leaf_tab[threadIdx.x] = 0ull; L.leaf_gid[threadIdx.x] = 0xffffffffu; }
+    L.nn_leaf[threadIdx.x >> 6][threadIdx.x & 63] = 0xffffffffu;
     if (threadIdx.x == 0) L.nfresh = 0;
     __syncthreads();
 
@@ -596,6 +598,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     refill(fc1, __builtin_amdgcn_readfirstlane(w1), P.ib1, P.fb1, 1);
                     refill(fc2, __builtin_amdgcn_readfirstlane(w2), P.ib2, P.fb2, 2);
                     update_cnn();
+                    L.nn_leaf[threadIdx.x >> 6][lane] = 0xffffffffu;   // relative leaf positions mean other leaves now
                     o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0);
                     o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1);
                     o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2);
@@ -616,7 +619,46 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
 
         // ---- leaf ids ----
-        if (!(P.ablate & 64u)) {
+        if (MODE == 1 && !(P.ablate & 64u)) {
+            // The leaf of a point is one of the 27 positions around the cached faces (nn); this wave's table
+            // in LDS says which leaf that is.  A plain LDS read per point; the lookup behind it runs once
+            // per position (and again after the face caches moved).
+            uint32_t *tab = L.nn_leaf[threadIdx.x >> 6];
+            uint32_t s0 = tab[o0.nn], s1 = tab[o1.nn], s2 = tab[o2.nn], s3 = tab[o3.nn];
+            const auto unknown = [](const PointOut &o, uint32_t sl) { return o.key != KEY_EMPTY && sl == 0xffffffffu; };
+            if (__ballot(unknown(o0, s0) || unknown(o1, s1) || unknown(o2, s2) || unknown(o3, s3)) != 0ull) {
+                for (;;) {
+                    const uint32_t want = unknown(o0, s0) ? o0.nn : unknown(o1, s1) ? o1.nn : unknown(o2, s2) ? o2.nn : unknown(o3, s3) ? o3.nn : 0xffu;
+                    const unsigned long long need = __ballot(want != 0xffu);
+                    if (!need) break;
+                    const int src = __ffsll((long long)need) - 1;
+                    const uint32_t nnv = (uint32_t)__builtin_amdgcn_readlane((int)want, src);
+                    const int q0 = fc0.mc - 1 + (int)(nnv & 3u), q1 = fc1.mc - 1 + (int)((nnv >> 2) & 3u), q2 = fc2.mc - 1 + (int)(nnv >> 4);
+                    uint32_t found = 0;
+                    if (lane == src) {
+                        found = P.local_leaves ? local_leaf_slot(L, pack_leaf(q0, q1, q2)) : leaf_lookup(W, P.leaf_mask, pack_leaf(q0, q1, q2));
+                        if (found != 0xffffffffu) tab[nnv] = found;
+                    }
+                    found = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
+                    if (found == 0xffffffffu) {
+                        // no room for this leaf: its points are dropped from this pass, the host runs another one
+                        if (P.local_leaves) err |= ERR_LOCAL_LEAVES;
+                        if (o0.nn == nnv) o0.key = KEY_EMPTY;
+                        if (o1.nn == nnv) o1.key = KEY_EMPTY;
+                        if (o2.nn == nnv) o2.key = KEY_EMPTY;
+                        if (o3.nn == nnv) o3.key = KEY_EMPTY;
+                    } else {
+                        if (o0.nn == nnv) s0 = found;
+                        if (o1.nn == nnv) s1 = found;
+                        if (o2.nn == nnv) s2 = found;
+                        if (o3.nn == nnv) s3 = found;
+                    }
+                }
+            }
+            // KEY_EMPTY stays all ones
+            o0.key |= s0 << CELL_BITS; o1.key |= s1 << CELL_BITS; o2.key |= s2 << CELL_BITS; o3.key |= s3 << CELL_BITS;
+        }
+        if (MODE != 1 && !(P.ablate & 64u)) {
             bool mism;
             if (MODE == 1) {
                 mism = (o0.key != KEY_EMPTY && o0.nn != cnn) || (o1.key != KEY_EMPTY && o1.nn != cnn) || (o2.key != KEY_EMPTY && o2.nn != cnn) ||
