@@ -939,7 +939,11 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ z, const float *__restrict__ bboxes,
                                                             uint32_t *__restrict__ ctrl, const unsigned long long *__restrict__ leaf_keys,
-                                                            uint32_t leaf_cap) {
+                                                            uint32_t leaf_cap, uint32_t *__restrict__ next_head, uint32_t next_head_words,
+                                                            uint32_t *__restrict__ host_out) {
+    // housekeeping this single workgroup has threads to spare for: zero the control block the NEXT call
+    // will use (the two blocks alternate, so no memset sits in front of the next call's first kernel)
+    for (uint32_t i = threadIdx.x; i < next_head_words; i += 1024) next_head[i] = 0u;
     __shared__ double s_mn[3], s_mx[3];
     __shared__ int s_resolved;
     __shared__ int s_depth;
@@ -984,6 +988,9 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
             if (d[0] * d[1] * d[2] > (long long)INT32_MAX) atomicOr(&ctrl[C_ERR], ERR_GRID_OVERFLOW);
             for (int a = 0; a < 3; a++) { ctrl[C_MINB + a] = (uint32_t)minb[a]; ctrl[C_DIVB + a] = (uint32_t)divb[a]; }
         }
+        __syncthreads();
+        // results straight into the host's pinned words: the host only waits for the stream
+        if (tid < C_WORDS) host_out[tid] = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 
@@ -1155,6 +1162,8 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
             ctrl[C_SHIFT + 2 * a + 1] = (uint32_t)((unsigned long long)s_shift[a] >> 32);
         }
     }
+    __syncthreads();
+    if (tid < C_WORDS) host_out[tid] = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------
@@ -1393,8 +1402,10 @@ struct Workspace {
     uint32_t leaf_cap = 0;     // leaf hash capacity = number of grids (power of two)
     size_t list_cap = 0;
     size_t bbox_cap = 0;
-    void *head = nullptr;              // ctrl | leaf_keys | seg_count, one block so that one memset resets it
-    size_t head_bytes = 0;
+    void *head = nullptr;              // two blocks of ctrl | leaf_keys | seg_count, used by alternate passes
+    size_t head_bytes = 0;             // bytes of one block
+    int parity = 0;                    // block of the next pass
+    bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
     unsigned long long *leaf_keys = nullptr;
     unsigned long long *records = nullptr;
     uint32_t *occupied = nullptr;
@@ -1447,10 +1458,10 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr;
         ws.records = nullptr; ws.bitmaps = nullptr; ws.leaf_cap = 0;
         ws.head_bytes = HEAD_CTRL_BYTES + (size_t)leaf_cap * 8 + (size_t)leaf_cap * RANK_SEGS * sizeof(uint32_t);
-        CW_HIP_TRY(hipMalloc(&ws.head, ws.head_bytes));
-        ws.ctrl = (uint32_t *)ws.head;
-        ws.leaf_keys = (unsigned long long *)((char *)ws.head + HEAD_CTRL_BYTES);
-        ws.seg_count = (uint32_t *)((char *)ws.head + HEAD_CTRL_BYTES + (size_t)leaf_cap * 8);
+        ws.head_bytes = (ws.head_bytes + 255) & ~(size_t)255;
+        CW_HIP_TRY(hipMalloc(&ws.head, 2 * ws.head_bytes));
+        ws.head_clean[0] = ws.head_clean[1] = false;
+        ws.parity = 0;
         CW_HIP_TRY(hipMalloc((void **)&ws.bitmaps, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t)));
         CW_HIP_TRY(hipMemsetAsync(ws.bitmaps, 0, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t), s));
         CW_HIP_TRY(hipMalloc((void **)&ws.records, (size_t)leaf_cap * GRID_BYTES));
@@ -1556,9 +1567,16 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
+        // control words, leaf table, slice counts: this pass's block (zeroed by the previous pass's replay kernel)
+        const int blk = ws.parity;
+        char *head = (char *)ws.head + (size_t)blk * ws.head_bytes, *next_head = (char *)ws.head + (size_t)(1 - blk) * ws.head_bytes;
+        ws.ctrl = (uint32_t *)head;
+        ws.leaf_keys = (unsigned long long *)(head + HEAD_CTRL_BYTES);
+        ws.seg_count = (uint32_t *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8);
         VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count};
-
-        bool ok = hipMemsetAsync(ws.head, 0, ws.head_bytes, c.stream) == hipSuccess;   // control words, leaf table, slice counts
+        bool ok = true;
+        if (!ws.head_clean[blk]) ok = hipMemsetAsync(head, 0, ws.head_bytes, c.stream) == hipSuccess;
+        ws.head_clean[blk] = false;
         if (ok && mode == 1 && !(ws.faces_valid && memcmp(ws.faces_host, faces_host, sizeof(faces_host)) == 0)) {
             float *stage = (float *)c.staging(sizeof(faces_host));
             ok = stage != nullptr;
@@ -1596,8 +1614,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         }
         const size_t replay_lds = (leaf_split && nwaves <= REPLAY_LDS_RANGES) ? nwaves * 6 * sizeof(float) : 0;
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), replay_lds, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
-                  ws.leaf_keys, ws.leaf_cap);
-        ok = hipMemcpyAsync(c.host_words, ws.ctrl, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+                  ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), c.host_words);
+        ok = hipGetLastError() == hipSuccess;
+        ws.head_clean[1 - blk] = ok;
+        ws.parity = 1 - blk;
         ok = c.sync() && ok;
         if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
