@@ -81,10 +81,24 @@ __global__ void __launch_bounds__(BLK) cell_count_kernel(Grid g, const float *__
 }
 
 __global__ void __launch_bounds__(BLK) count_nonzero_kernel(const uint32_t *__restrict__ counts, size_t ncells, uint32_t *__restrict__ out) {
+    // one atomic per workgroup: thousands of adds to one address serialise (about 6 ns each)
+    __shared__ uint32_t wsum[BLK / 64];
     uint32_t c = 0;
-    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < ncells; i += (size_t)gridDim.x * BLK) c += counts[i] != 0;
+    const size_t nvec = ncells / 4;
+    const uint4 *v = reinterpret_cast<const uint4 *>(counts);
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nvec; i += (size_t)gridDim.x * BLK) {
+        const uint4 q = v[i];
+        c += (q.x != 0) + (q.y != 0) + (q.z != 0) + (q.w != 0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (ncells & 3)) c += counts[nvec * 4 + threadIdx.x] != 0;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < BLK / 64; w++) t += wsum[w];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 // sorted[pos] = (x, y, z, original index)
@@ -169,6 +183,73 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid g, const float4 
     }
     double sum = 0.0;
     for (int j = 1; j < have; j++) sum += (double)sqrtf(best[j * QB]);
+    dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
+}
+
+// The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
+// compare-exchange chain, no LDS round trips per accepted candidate.  Unused leading slots hold -inf,
+// so the largest kept distance is always the last register.
+template <int KCAP>
+__global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const float4 *__restrict__ sorted, size_t n, const uint32_t *__restrict__ cell_start,
+                                                              const uint32_t *__restrict__ cell_count, int k, float *__restrict__ dist_out) {
+    const int want = k + 1, pad = KCAP - want;
+    size_t qi = (size_t)blockIdx.x * QB + threadIdx.x;
+    if (qi >= n) return;
+    const float4 q = sorted[qi];
+    const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+    float best[KCAP];
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) best[j] = j < pad ? -INFINITY : INFINITY;
+    int have = 0;
+    const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int ring = 0; ring <= maxring; ring++) {
+        for (int dz = -ring; dz <= ring; dz++) {
+            const int z = cz + dz;
+            if (z < 0 || z >= g.dim[2]) continue;
+            for (int dy = -ring; dy <= ring; dy++) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.dim[1]) continue;
+                const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
+                const int step = face ? 1 : (ring > 0 ? 2 * ring : 1);
+                for (int dx = -ring; dx <= ring; dx += step) {
+                    const int x = cx + dx;
+                    if (x < 0 || x >= g.dim[0]) continue;
+                    const uint32_t c = (uint32_t)x + (uint32_t)g.dim[0] * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
+                    const uint32_t first = cell_start[c], cnt = cell_count[c];
+                    for (uint32_t e = first; e < first + cnt; e++) {
+                        const float4 p = sorted[e];
+                        // FLANN L2_Simple<float>: separately rounded fp32 operations, x,y,z order
+                        float d = __fsub_rn(q.x, p.x);
+                        float d2 = __fmul_rn(d, d);
+                        d = __fsub_rn(q.y, p.y);
+                        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+                        d = __fsub_rn(q.z, p.z);
+                        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+                        if (d2 < best[KCAP - 1]) {
+                            have++;
+                            float v = d2;   // sorted insert: the last register's old value drops out
+#pragma unroll
+                            for (int j = 0; j < KCAP; j++) {
+                                const float lo = fminf(best[j], v);
+                                v = fmaxf(best[j], v);
+                                best[j] = lo;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (have >= want) {
+            const double reach = (double)ring * g.h;
+            if ((double)best[KCAP - 1] < reach * reach * (1.0 - 1e-6)) break;
+        }
+    }
+    // the f64 sum of fp32 square roots in ascending order, skipping the query itself (the smallest)
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 1; j < KCAP; j++) {
+        if (j > pad && best[j] < INFINITY) sum += (double)sqrtf(best[j]);
+    }
     dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
 }
 
@@ -257,8 +338,10 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     };
     auto cells_of = [](const Grid &g) { return (size_t)g.dim[0] * (size_t)g.dim[1] * (size_t)g.dim[2]; };
     // finest cell size whose dense grid stays within MAX_CELLS
+    // (and, for small clouds, within a few cells per point: the probe is a pass over the grid)
+    const size_t probe_cells = std::min<size_t>(MAX_CELLS, std::max<size_t>((size_t)1 << 16, 8 * n));
     double h_min = maxext / 1024.0;
-    while (cells_of(make_grid(h_min)) > MAX_CELLS) h_min *= 1.25;
+    while (cells_of(make_grid(h_min)) > probe_cells) h_min *= 1.25;
 
     uint32_t *counts = (uint32_t *)pool_alloc(MAX_CELLS * sizeof(uint32_t) + 256);
     uint32_t *fill = (uint32_t *)pool_alloc(MAX_CELLS * sizeof(uint32_t));
@@ -277,7 +360,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
          hipMemsetAsync(occ_dev, 0, sizeof(uint32_t), c.stream) == hipSuccess;
     if (ok) {
         CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, src.x(), src.y(), src.z(), n, counts, cell_id);
-        CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(grid_for(ncells)), dim3(BLK), 0, c.stream, counts, ncells, occ_dev);
+        CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(std::min(1024u, grid_for(ncells / 4 + 1))), dim3(BLK), 0, c.stream, counts, ncells, occ_dev);
         ok = hipMemcpyAsync(c.host_words, occ_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
     }
     ok = c.sync() && ok;
@@ -321,7 +404,13 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         // 4. the k-NN pass
         const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
         const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
-        CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+        if (k + 1 <= 17) {
+            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_reg_kernel<17>, dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+        } else if (k + 1 <= 33) {
+            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_reg_kernel<33>, dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+        } else {
+            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+        }
     }
     ok = c.sync() && ok;
     pool_free(cursor);
