@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
+#include <vector>
 #include <unordered_map>
 
 namespace cwipc_amd {
@@ -113,6 +115,83 @@ void *pool_alloc(size_t bytes) {
     g_pool_live[p] = {dev, cls};
     g_pool_bytes += cls;
     return p;
+}
+
+// ---------------------------------------------------------------------------
+// pinned host pool, parallel memcpy
+// ---------------------------------------------------------------------------
+namespace {
+std::mutex g_host_mutex;
+std::map<size_t, std::vector<void *>> g_host_free;     // class -> page-locked blocks
+std::unordered_map<void *, size_t> g_host_live;        // block -> class
+size_t g_host_cached_bytes = 0;
+constexpr size_t HOST_CACHE_LIMIT = (size_t)4 << 30;   // page-locked memory kept for reuse
+}  // namespace
+
+void *host_alloc(size_t bytes, bool *pinned) {
+    *pinned = false;
+    if (bytes < ((size_t)1 << 16) || device_count() < 1) return malloc(bytes ? bytes : 1);   // small buffers: pinning does not pay
+    const size_t cls = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        auto it = g_host_free.find(cls);
+        if (it != g_host_free.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_host_cached_bytes -= cls;
+            g_host_live[p] = cls;
+            *pinned = true;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return malloc(bytes ? bytes : 1);
+    }
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    g_host_live[p] = cls;
+    *pinned = true;
+    return p;
+}
+
+void host_free(void *ptr, bool pinned) {
+    if (!ptr) return;
+    if (!pinned) { ::free(ptr); return; }
+    size_t cls = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        auto it = g_host_live.find(ptr);
+        if (it == g_host_live.end()) return;
+        cls = it->second;
+        g_host_live.erase(it);
+        if (g_host_cached_bytes + cls <= HOST_CACHE_LIMIT) {
+            g_host_free[cls].push_back(ptr);
+            g_host_cached_bytes += cls;
+            keep = true;
+        }
+    }
+    if (!keep) (void)hipHostFree(ptr);
+}
+
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t piece = (size_t)8 << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = bytes / piece;
+    if (nthreads > 4) nthreads = 4;
+    if (hw && nthreads > hw) nthreads = hw;
+    if (nthreads < 2) { memcpy(dst, src, bytes); return; }
+    const size_t per = ((bytes / nthreads) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < nthreads; t++) {
+        const size_t off = t * per;
+        if (off >= bytes) break;
+        const size_t len = off + per < bytes ? per : bytes - off;
+        workers.emplace_back([=]() { memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    memcpy(dst, src, per < bytes ? per : bytes);
+    for (auto &w : workers) w.join();
 }
 
 void pool_free(void *ptr) {
@@ -311,6 +390,14 @@ extern "C" size_t cwipc_hip_pool_bytes(void) {
 }
 
 extern "C" void cwipc_hip_pool_trim(void) {
+    {
+        std::lock_guard<std::mutex> lock(g_host_mutex);
+        for (auto &kv : g_host_free) {
+            for (void *p : kv.second) (void)hipHostFree(p);
+            kv.second.clear();
+        }
+        g_host_cached_bytes = 0;
+    }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &kv : g_pool_free) {
         for (void *p : kv.second) {

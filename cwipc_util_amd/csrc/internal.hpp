@@ -144,11 +144,19 @@ struct DeviceSoA {
 };
 std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints);
 
-// Host representation: malloc'd AoS exactly as handed in through the C-ABI.
+// Host memory for point buffers: page-locked and pooled when a GPU is there (the DMA engines then
+// read and write it directly, no staging copy), plain malloc otherwise.
+void *host_alloc(size_t bytes, bool *pinned);
+void host_free(void *ptr, bool pinned);
+// memcpy split over a few threads for buffers of many megabytes (one core copies at ~10 GB/s)
+void parallel_memcpy(void *dst, const void *src, size_t bytes);
+
+// Host representation: AoS exactly as handed in through the C-ABI.
 struct HostAoS {
     cwipc_point *points = nullptr;
     size_t npoints = 0;
-    ~HostAoS() { ::free(points); }
+    bool pinned = false;
+    ~HostAoS() { host_free(points, pinned); }
 };
 
 // The cwipc_pointcloud implementation.  Either representation may be missing;
@@ -186,7 +194,7 @@ public:
     bool has_data() const { return m_has_data; }
 
 private:
-    int copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact);
+    int copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact, bool dst_pinned = false);
     std::mutex m_lock;
     uint64_t m_timestamp = 0;
     float m_cellsize = 0;

@@ -15,6 +15,7 @@
 // radius r proves exactness once the (k+1)-th distance is <= r*h.
 #include "internal.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 
@@ -201,39 +202,71 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
 #pragma unroll
     for (int j = 0; j < KCAP; j++) best[j] = j < pad ? -INFINITY : INFINITY;
     int have = 0;
-    const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
-    for (int ring = 0; ring <= maxring; ring++) {
-        for (int dz = -ring; dz <= ring; dz++) {
-            const int z = cz + dz;
-            if (z < 0 || z >= g.dim[2]) continue;
-            for (int dy = -ring; dy <= ring; dy++) {
-                const int y = cy + dy;
-                if (y < 0 || y >= g.dim[1]) continue;
-                const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
-                const int step = face ? 1 : (ring > 0 ? 2 * ring : 1);
-                for (int dx = -ring; dx <= ring; dx += step) {
-                    const int x = cx + dx;
-                    if (x < 0 || x >= g.dim[0]) continue;
-                    const uint32_t c = (uint32_t)x + (uint32_t)g.dim[0] * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
-                    const uint32_t first = cell_start[c], cnt = cell_count[c];
-                    for (uint32_t e = first; e < first + cnt; e++) {
-                        const float4 p = sorted[e];
-                        // FLANN L2_Simple<float>: separately rounded fp32 operations, x,y,z order
-                        float d = __fsub_rn(q.x, p.x);
-                        float d2 = __fmul_rn(d, d);
-                        d = __fsub_rn(q.y, p.y);
-                        d2 = __fadd_rn(d2, __fmul_rn(d, d));
-                        d = __fsub_rn(q.z, p.z);
-                        d2 = __fadd_rn(d2, __fmul_rn(d, d));
-                        if (d2 < best[KCAP - 1]) {
-                            have++;
-                            float v = d2;   // sorted insert: the last register's old value drops out
+    // one candidate: FLANN L2_Simple<float> distance (separately rounded fp32 operations, x,y,z order), sorted insert
+    auto candidate = [&](const float4 p) {
+        float d = __fsub_rn(q.x, p.x);
+        float d2 = __fmul_rn(d, d);
+        d = __fsub_rn(q.y, p.y);
+        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+        d = __fsub_rn(q.z, p.z);
+        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+        if (d2 < best[KCAP - 1]) {
+            have++;
+            float v = d2;   // the last register's old value drops out
 #pragma unroll
-                            for (int j = 0; j < KCAP; j++) {
-                                const float lo = fminf(best[j], v);
-                                v = fmaxf(best[j], v);
-                                best[j] = lo;
-                            }
+            for (int j = 0; j < KCAP; j++) {
+                const float lo = fminf(best[j], v);
+                v = fmaxf(best[j], v);
+                best[j] = lo;
+            }
+        }
+    };
+    // Cells that are neighbours along x are neighbours in `sorted` (the counting sort runs x fastest), so a
+    // row of cells x0..x1 is ONE range of points: two index loads per row instead of two per cell.
+    auto row_range = [&](int x0, int x1, int y, int z, uint32_t &first, uint32_t &last) {
+        const uint32_t base = (uint32_t)g.dim[0] * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
+        const uint32_t c1 = base + (uint32_t)x1;
+        first = cell_start[base + (uint32_t)x0];
+        last = cell_start[c1] + cell_count[c1];
+    };
+    // rings 0 and 1 together: 9 rows, their index loads issued before any of them is needed
+    {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        uint32_t first[9], last[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+            first[r] = last[r] = 0;
+            if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) row_range(x0, x1, y, z, first[r], last[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            for (uint32_t e = first[r]; e < last[r]; e++) candidate(sorted[e]);
+        }
+    }
+    const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int ring = 1; ring <= maxring; ring++) {
+        if (ring > 1) {
+            const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dim[0] - 1);
+            for (int dz = -ring; dz <= ring; dz++) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.dim[2]) continue;
+                for (int dy = -ring; dy <= ring; dy++) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.dim[1]) continue;
+                    const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
+                    uint32_t first, last;
+                    if (face) {   // the whole row belongs to the shell
+                        row_range(x0, x1, y, z, first, last);
+                        for (uint32_t e = first; e < last; e++) candidate(sorted[e]);
+                    } else {      // only its two end cells do
+                        if (cx - ring >= 0) {
+                            row_range(cx - ring, cx - ring, y, z, first, last);
+                            for (uint32_t e = first; e < last; e++) candidate(sorted[e]);
+                        }
+                        if (cx + ring < g.dim[0]) {
+                            row_range(cx + ring, cx + ring, y, z, first, last);
+                            for (uint32_t e = first; e < last; e++) candidate(sorted[e]);
                         }
                     }
                 }
@@ -366,7 +399,8 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     ok = c.sync() && ok;
     if (!ok) { cleanup(); return false; }
     double ppc = (double)n / (double)(c.host_words[0] ? c.host_words[0] : 1);
-    double target = (double)(k + 1) / 3.0;
+    double target = (double)(k + 1) / 2.0;
+    if (const char *t = getenv("CWIPC_SOR_CELL_TARGET")) target = (double)(k + 1) * atof(t);   // tuning knob: points per occupied cell / (k + 1)
     if (ppc < target) {
         double h = h_min * sqrt(target / ppc);
         if (h > maxext) h = maxext;

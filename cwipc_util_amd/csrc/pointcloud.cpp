@@ -157,7 +157,7 @@ int cwipc_hip_pointcloud::copy_uncompressed(struct cwipc_point *pointbuf, size_t
     return copy_impl(pointbuf, size, m_exact_size);
 }
 
-int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact) {
+int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact, bool dst_pinned) {
     if (!m_has_data) {
         cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_util", "copy_uncompressed: NULL pointcloud");
         return 0;
@@ -171,7 +171,7 @@ int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, b
     {
         std::lock_guard<std::mutex> lock(m_lock);
         if (m_host) {
-            memcpy(pointbuf, m_host->points, need);
+            parallel_memcpy(pointbuf, m_host->points, need);
             return (int)m_npoints;
         }
     }
@@ -188,7 +188,8 @@ int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, b
     if (!aos) return -1;
     dev->wait_on(c.stream);
     k::soa_to_aos(*dev, (cwipc_point *)aos, m_npoints, c.stream);
-    void *stage = c.staging(need);
+    // a page-locked destination (our own host copy) is written by the DMA engine directly
+    void *stage = dst_pinned ? (void *)pointbuf : c.staging(need);
     bool ok = stage != nullptr;
     if (ok) ok = hipMemcpyAsync(stage, aos, need, hipMemcpyDeviceToHost, c.stream) == hipSuccess;
     ok = c.sync() && ok;
@@ -197,7 +198,7 @@ int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, b
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "copy_uncompressed: device to host copy failed");
         return -1;
     }
-    memcpy(pointbuf, stage, need);
+    if (!dst_pinned) parallel_memcpy(pointbuf, stage, need);
     return (int)m_npoints;
 }
 
@@ -242,12 +243,12 @@ int cwipc_hip_pointcloud::from_points(const cwipc_point *points, size_t size, in
     }
     auto host = std::make_shared<HostAoS>();
     host->npoints = (size_t)npoint;
-    host->points = (cwipc_point *)malloc(size ? size : 1);
+    host->points = (cwipc_point *)host_alloc(size, &host->pinned);
     if (!host->points) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "from_points: could not allocate memory for points, size=" + std::to_string(size));
         return -1;
     }
-    if (size) memcpy(host->points, points, size);
+    if (size) parallel_memcpy(host->points, points, size);
     std::lock_guard<std::mutex> lock(m_lock);
     m_timestamp = timestamp;
     m_npoints = (size_t)npoint;
@@ -305,7 +306,10 @@ std::shared_ptr<DeviceSoA> cwipc_hip_pointcloud::device_points() {
         // chunk i+1 overlaps the DMA of chunk i.
         const size_t chunk = (size_t)16 << 20;
         bool ok = true;
-        if (bytes <= chunk) {
+        if (host->pinned) {
+            // page-locked already: the DMA engine reads the cloud where it lies
+            ok = hipMemcpyAsync(aos, host->points, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess;
+        } else if (bytes <= chunk) {
             void *stage = c.staging(bytes);
             ok = stage != nullptr;
             if (ok) {
@@ -362,10 +366,10 @@ std::shared_ptr<HostAoS> cwipc_hip_pointcloud::host_points() {
     auto host = std::make_shared<HostAoS>();
     host->npoints = m_npoints;
     size_t bytes = m_npoints * sizeof(cwipc_point);
-    host->points = (cwipc_point *)malloc(bytes ? bytes : 1);
+    host->points = (cwipc_point *)host_alloc(bytes, &host->pinned);
     if (!host->points) return nullptr;
     if (bytes) {
-        int n = copy_impl(host->points, bytes, false);
+        int n = copy_impl(host->points, bytes, false, host->pinned);
         if (n < 0) return nullptr;
     }
     std::lock_guard<std::mutex> lock(m_lock);
