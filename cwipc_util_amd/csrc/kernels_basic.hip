@@ -187,38 +187,54 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
                                                                const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
                                                                const uint32_t *__restrict__ block_offsets, float *__restrict__ ox,
                                                                float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
-    __shared__ uint32_t wave_sum[WAVES];
+    __shared__ uint32_t wave_sum[STEPS][WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    size_t tile0 = (size_t)blockIdx.x * TILE;
-    size_t out = block_offsets[blockIdx.x];
-#pragma unroll 1
+    const size_t tile0 = (size_t)blockIdx.x * TILE;
+    const size_t out0 = block_offsets[blockIdx.x];
+    // the whole tile is loaded before anything else happens (16 loads of 16 B per lane in flight);
+    // the scatter needs all four planes of the kept points
+    float4 vx[STEPS], vy[STEPS], vz[STEPS];
+    uint4 vw[STEPS];
+    unsigned m[STEPS];
+    uint32_t inc[STEPS];
+#pragma unroll
     for (int s = 0; s < STEPS; s++) {
-        size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
-        float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
-        uint4 vw = make_uint4(0, 0, 0, 0);
-        // the scatter needs all four planes of the kept points
-        unsigned m = lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
-        uint32_t c = __popc(m);
-        // wave-inclusive prefix of the per-lane keep counts
-        uint32_t inc = c;
+        const size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
+        vx[s] = make_float4(0, 0, 0, 0); vy[s] = vx[s]; vz[s] = vx[s];
+        vw[s] = make_uint4(0, 0, 0, 0);
+        m[s] = lane_mask<true>(p, x, y, z, rgbt, base, n, vx[s], vy[s], vz[s], vw[s]);
+        inc[s] = __popc(m[s]);
+    }
+    // ranks inside the tile (points run step-major, then lane-major): wave prefixes, one barrier
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        const uint32_t c = inc[s];
         for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
+            const uint32_t t = __shfl_up(inc[s], off, 64);
+            if (lane >= off) inc[s] += t;
         }
-        if (lane == 63) wave_sum[wave] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, total = 0;
+        if (lane == 63) wave_sum[s][wave] = inc[s];
+        inc[s] -= c;   // exclusive inside the wave
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        uint32_t before = 0, tot = 0;
+#pragma unroll
         for (int w = 0; w < WAVES; w++) {
-            uint32_t t = wave_sum[w];
-            if (w < wave) wbase += t;
-            total += t;
+            const uint32_t t = wave_sum[s][w];
+            if (w < wave) before += t;
+            tot += t;
         }
-        size_t pos = out + wbase + inc - c;
-        const float ax[4] = {vx.x, vx.y, vx.z, vx.w}, ay[4] = {vy.x, vy.y, vy.z, vy.w}, az[4] = {vz.x, vz.y, vz.z, vz.w};
-        const uint32_t aw[4] = {vw.x, vw.y, vw.z, vw.w};
+        size_t pos = out0 + run + before + inc[s];
+        run += tot;
+        const float ax[4] = {vx[s].x, vx[s].y, vx[s].z, vx[s].w}, ay[4] = {vy[s].x, vy[s].y, vy[s].z, vy[s].w};
+        const float az[4] = {vz[s].x, vz[s].y, vz[s].z, vz[s].w};
+        const uint32_t aw[4] = {vw[s].x, vw[s].y, vw[s].z, vw[s].w};
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
-            if (m & (1u << j)) {
+            if (m[s] & (1u << j)) {
                 ox[pos] = ax[j];
                 oy[pos] = ay[j];
                 oz[pos] = az[j];
@@ -226,8 +242,6 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
                 pos++;
             }
         }
-        out += total;
-        __syncthreads();
     }
 }
 
