@@ -251,8 +251,10 @@ __device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t li
         mark_occupied(W, key);
         atomicAdd(&W.seg_count[slice_of(key)], 1u);
         const uint32_t idx = atomicAdd(&W.ctrl[C_COUNT], 1u);
-        if (idx < list_cap) W.occupied[idx] = key;
-        else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+        if (list_cap) {   // 0: the caller does not keep the list
+            if (idx < list_cap) W.occupied[idx] = key;
+            else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+        }
     }
 }
 
@@ -299,6 +301,7 @@ struct K1Params {
     int fb0, fb1, fb2;
     uint32_t leaf_mask, list_cap, ablate;
     uint32_t local_leaves;   // 1: keys carry workgroup-local leaf slots (no global memory access in the hot loop)
+    uint32_t want_list;      // 1: the touched records are listed in W.occupied (plain grid: the sort needs them); 0: only counted
     uint32_t q_bias;    // per-point bias of the offset sums
     float q_round;      // q_bias + 0.5 (the offset is biased and rounded by one fma, then truncated)
     float g_check;      // |coordinate * inv_leaf| a wave may see at this scale (inf: no limit)
@@ -323,6 +326,18 @@ __device__ __forceinline__ uint32_t local_leaf_slot(LdsTable &L, unsigned long l
         pos = (pos + 1) & (LOCAL_LEAVES - 1);
     }
     return 0xffffffffu;
+}
+
+// One lane: leaf k as the hot loop names it (a local slot, or the global id).  Whoever creates a local
+// slot also fetches its global id right away, while the other waves keep streaming: the flush at the end
+// of the kernel is a serial tail and should not start with a round trip to the global leaf table.
+__device__ __forceinline__ uint32_t leaf_name(LdsTable &L, const VoxWork &W, const K1Params &P, unsigned long long k) {
+    if (!P.local_leaves) return leaf_lookup(W, P.leaf_mask, k);
+    const uint32_t slot = local_leaf_slot(L, k);
+    if (slot != 0xffffffffu && atomicCAS(&L.leaf_gid[slot], 0xffffffffu, 0xfffffffeu) == 0xffffffffu) {
+        L.leaf_gid[slot] = leaf_lookup(W, P.leaf_mask, k);   // ~0 if the global table is full (ERR_LEAVES is set then)
+    }
+    return slot;
 }
 
 __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const K1Params &P, const Run32 &r, bool active) {
@@ -361,7 +376,7 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
             gkey = (gid << CELL_BITS) | (r.key & ((1u << CELL_BITS) - 1));
             if (gid == 0xffffffffu) return;   // ERR_LEAVES is set: the pass is discarded
         }
-        global_insert_lane(W, P.list_cap, gkey, (long long)r.qx - bias, (long long)r.qy - bias, (long long)r.qz - bias, u64_of(r.cr & 0xffffu, cnt),
+        global_insert_lane(W, P.want_list ? P.list_cap : 0u, gkey, (long long)r.qx - bias, (long long)r.qy - bias, (long long)r.qz - bias, u64_of(r.cr & 0xffffu, cnt),
                            u64_of(r.gb & 0xffffu, r.gb >> 16), r.tile);
     }
 }
@@ -636,7 +651,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     const int q0 = fc0.mc - 1 + (int)(nnv & 3u), q1 = fc1.mc - 1 + (int)((nnv >> 2) & 3u), q2 = fc2.mc - 1 + (int)(nnv >> 4);
                     uint32_t found = 0;
                     if (lane == src) {
-                        found = P.local_leaves ? local_leaf_slot(L, pack_leaf(q0, q1, q2)) : leaf_lookup(W, P.leaf_mask, pack_leaf(q0, q1, q2));
+                        found = leaf_name(L, W, P, pack_leaf(q0, q1, q2));
                         if (found != 0xffffffffu) tab[nnv] = found;
                     }
                     found = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
@@ -696,7 +711,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     const int s0 = __builtin_amdgcn_readlane(m0, src), s1 = __builtin_amdgcn_readlane(m1, src), s2 = __builtin_amdgcn_readlane(m2, src);
                     if (!(cache_valid && s0 == cl0 && s1 == cl1 && s2 == cl2)) {
                         uint32_t found = 0;
-                        if (lane == src) found = P.local_leaves ? local_leaf_slot(L, pack_leaf(s0, s1, s2)) : leaf_lookup(W, P.leaf_mask, pack_leaf(s0, s1, s2));
+                        if (lane == src) found = leaf_name(L, W, P, pack_leaf(s0, s1, s2));
                         cache_id = (uint32_t)__builtin_amdgcn_readlane((int)found, src);
                         if (P.local_leaves && cache_id == 0xffffffffu) err |= ERR_LOCAL_LEAVES;
                         cl0 = s0; cl1 = s1; cl2 = s2;
@@ -862,8 +877,9 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     if (P.local_leaves) {
         // local leaf slots -> global leaf ids (grids), one lookup per leaf and workgroup
         if (threadIdx.x < LOCAL_LEAVES) {
+            // normally all there already (leaf_name); only a lookup that failed is tried again
             const unsigned long long lk = L.leaf_tab[threadIdx.x];
-            if (lk != 0ull) L.leaf_gid[threadIdx.x] = leaf_lookup(W, P.leaf_mask, lk);
+            if (lk != 0ull && L.leaf_gid[threadIdx.x] >= 0xfffffffeu) L.leaf_gid[threadIdx.x] = leaf_lookup(W, P.leaf_mask, lk);
         }
         __syncthreads();
     }
@@ -910,7 +926,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         const uint32_t k = fkey[it];
         if (sub == 3 && k != KEY_EMPTY && (fold[it] >> 32) == 0) {
             // first touch of this record in this call: list it, set its bit, count it in its bitmap slice
-            L.fresh[atomicAdd(&L.nfresh, 1u)] = k;
+            const uint32_t at = atomicAdd(&L.nfresh, 1u);
+            if (P.want_list) L.fresh[at] = k;
             mark_occupied(W, k);
             const uint32_t sl = slice_of(k), hs = sl & 63u;
             const uint32_t tag = atomicCAS(&L.htag[hs], 0u, sl + 1u);
@@ -921,6 +938,12 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     __syncthreads();
     if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.seg_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
     const uint32_t nfresh = L.nfresh;
+    if (!P.want_list) {
+        // octree path: the finalize pass finds the records through the occupancy bitmaps, so the count is
+        // all that is needed here, and nobody waits for this add
+        if (threadIdx.x == 0 && nfresh) atomicAdd(&W.ctrl[C_COUNT], nfresh);
+        return;
+    }
     if (threadIdx.x == 0 && nfresh) L.fresh_base = atomicAdd(&W.ctrl[C_COUNT], nfresh);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nfresh; i += K1_THREADS) {
@@ -1394,6 +1417,27 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
     }
 }
 
+// Error path of the octree variant (no list of touched records there): zero every record whose bit is
+// set, and the bitmaps.  Same launch shape as rank_emit_kernel.
+__global__ void __launch_bounds__(RANK_THREADS) clean_by_bitmap_kernel(VoxWork W) {
+    const uint32_t p = blockIdx.x / RANK_SEGS, seg = blockIdx.x % RANK_SEGS;
+    if (W.leaf_keys[p] == 0ull) return;
+    uint32_t *bm = W.bitmaps + (size_t)p * BITWORDS;
+    const int w_lo = (int)seg * SEG_WORDS, w_hi = min(w_lo + SEG_WORDS, BITWORDS);
+    for (int w = w_lo + threadIdx.x; w < w_hi; w += RANK_THREADS) {
+        uint32_t bits = bm[w];
+        if (!bits) continue;
+        bm[w] = 0u;
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(record_ptr(W, (p << CELL_BITS) | (uint32_t)(w * 32 + b)));
+            const ulonglong2 zero = {0ull, 0ull};
+            rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------
@@ -1598,6 +1642,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         K.leaf_mask = P.leaf_mask; K.list_cap = P.list_cap; K.ablate = P.ablate;
         K.q_bias = wide ? Q_BIAS_WIDE : Q_BIAS;
         K.local_leaves = local_leaves ? 1u : 0u;
+        K.want_list = leaf_split ? 0u : 1u;
         K.q_round = (float)K.q_bias + 0.5f;
         K.g_check = wide ? G_CHECK_WIDE : G_CHECK;
         K.mn0[0] = P.mn0[0]; K.mn0[1] = P.mn0[1]; K.mn0[2] = P.mn0[2];
@@ -1676,9 +1721,14 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 }
             }
         }
-        if (m && !ranked) {
+        if (leaf_split && !ranked) {
+            // octree variant, error: the records must be left zeroed
+            CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
+            ok = c.sync() && ok;
+        }
+        if (!leaf_split && m) {
             // emit (or, on error, only clean): the records must be left zeroed either way
-            const int emit = (!err && dst && !leaf_split) ? 1 : 0;
+            const int emit = (!err && dst) ? 1 : 0;
             CW_LAUNCH("emit_and_clean", emit_and_clean_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, vals_out, emit ? dst->x() : nullptr,
                       emit ? dst->y() : nullptr, emit ? dst->z() : nullptr, emit ? dst->rgbt() : nullptr, emit);
             if (emit) ok = hipMemcpyAsync(c.host_words, ws.ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
