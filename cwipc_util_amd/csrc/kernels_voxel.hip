@@ -109,7 +109,12 @@ enum : uint32_t {
 };
 
 // control block, 32-bit words in device memory
-enum { C_ERR = 0, C_COUNT = 1, C_DEPTH = 2, C_EVENTS = 3, C_SHIFT = 4 /* 3 x int64 */, C_MINB = 10, C_DIVB = 13, C_WORDS = 32 };
+enum {
+    C_ERR = 0, C_COUNT = 1, C_DEPTH = 2, C_EVENTS = 3, C_SHIFT = 4 /* 3 x int64 */, C_MINB = 10, C_DIVB = 13,
+    C_FALLBACK = 16,   // runs that found the workgroup table full and went to the global records one lane at a time
+    C_MAXLOAD = 17,    // fullest workgroup table (entries)
+    C_WORDS = 32
+};
 
 struct VoxParams {
     size_t n;
@@ -288,6 +293,7 @@ struct LdsTable {
     float faces[3 * FACES];
     uint32_t htag[64], hcnt[64];  // first touches per bitmap slice of this workgroup (slice + 1, count)
     uint32_t nfresh, fresh_base;
+    uint32_t nfallback, nused;    // table-full fallbacks of this workgroup; entries in use (counted by the flush)
     unsigned long long leaf_tab[LOCAL_LEAVES];   // packed leaf coordinates, 0 = free; position = local leaf slot
     uint32_t leaf_gid[LOCAL_LEAVES];             // global leaf id of each slot (filled before the flush)
     uint32_t nn_leaf[K1_WAVES][64];              // per wave: leaf (slot or id) of each leaf position relative to the cached faces, ~0 = not looked up yet
@@ -367,7 +373,8 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
     if (__ballot(need_or) != 0ull) {
         if (need_or) atomicOr(&L.tile[slot], r.tile);
     }
-    if (active && pending) {   // table saturated (incoherent input): straight to the global records
+    if (active && pending) {   // table saturated (sparse or incoherent input): straight to the global records
+        atomicAdd(&L.nfallback, 1u);
         const uint32_t cnt = r.cr >> 16;
         const long long bias = (long long)cnt * P.q_bias;
         uint32_t gkey = r.key;
@@ -461,6 +468,41 @@ __device__ __forceinline__ PointOut point_key(const K1Params &P, const FaceCache
     return o;
 }
 
+// The same for a step whose voxels do not fit between one pair of cached faces per axis (a scan line
+// wrapping around, a sparse cloud): every point looks up the two faces next to its own voxel in the
+// threshold table in LDS.  Same arithmetic, same results, six LDS reads per point more.
+__device__ __forceinline__ PointOut point_key_lookup(const K1Params &P, const float *faces, float fx, float fy, float fz, bool present, bool &off_table) {
+    PointOut o;
+    o.nn = 0;
+    o.u0 = o.u1 = o.u2 = 0;
+    int c[3], l[3];
+    uint32_t q[3];
+    const float f[3] = {fx, fy, fz};
+    const int ib[3] = {P.ib0, P.ib1, P.ib2}, fb[3] = {P.fb0, P.fb1, P.fb2};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float g = floorf(__fmul_rn(f[a], P.inv_leaf));
+        const int t = (int)g - ib[a];
+        const int m = (t + 32) >> 6;                         // the face nearest to this voxel
+        const unsigned i = (unsigned)(m - fb[a]);
+        const bool in_table = i + 1u < (unsigned)FACES;
+        ok &= in_table;
+        const unsigned ii = in_table ? i : 0u;
+        const float tlo = faces[a * FACES + ii], thi = faces[a * FACES + ii + 1];
+        l[a] = m - 1 + (f[a] >= tlo ? 1 : 0) + (f[a] >= thi ? 1 : 0);
+        c[a] = t - 64 * l[a] + 2;
+        q[a] = (uint32_t)(int)fmaf(fmaf(-g, P.leaf, f[a]), P.fix_scale, P.q_round);
+    }
+    o.l0 = l[0]; o.l1 = l[1]; o.l2 = l[2];
+    o.q0 = q[0]; o.q1 = q[1]; o.q2 = q[2];
+    o.seen = present && __builtin_isfinite(fx + fy + fz);
+    off_table |= o.seen && !ok;
+    const uint32_t cm = max(max((uint32_t)c[0], (uint32_t)c[1]), (uint32_t)c[2]);
+    o.key = (o.seen && ok && cm < (uint32_t)GRID_DIM) ? (uint32_t)__umul24(__umul24((uint32_t)c[2], GRID_DIM) + (uint32_t)c[1], GRID_DIM) + (uint32_t)c[0] : KEY_EMPTY;
+    return o;
+}
+
 // r,g,b,tile bytes of one point as addends of the run sums: byte permutes instead of shifts and masks
 struct PointAdd {
     uint32_t cr;     // count << 16 | r
@@ -513,7 +555,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
     if (threadIdx.x < LOCAL_LEAVES) { L.leaf_tab[threadIdx.x] = 0ull; L.leaf_gid[threadIdx.x] = 0xffffffffu; }
     L.nn_leaf[threadIdx.x >> 6][threadIdx.x & 63] = 0xffffffffu;
-    if (threadIdx.x == 0) L.nfresh = 0;
+    if (threadIdx.x == 0) { L.nfresh = 0; L.nfallback = 0; L.nused = 0; }
     __syncthreads();
 
     // wave-uniform caches: two leaf faces per axis, the last leaf and its id
@@ -524,12 +566,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     int cl0 = 0, cl1 = 0, cl2 = 0;
     uint32_t cache_id = 0xffffffffu;
     bool cache_valid = false;
-    // the cached leaf relative to the cached faces, packed like PointOut::nn (0xff: not expressible, never equal)
-    uint32_t cnn = 0xffu;
-    auto update_cnn = [&]() {
-        const uint32_t r0 = (uint32_t)(cl0 - (fc0.mc - 1)), r1 = (uint32_t)(cl1 - (fc1.mc - 1)), r2 = (uint32_t)(cl2 - (fc2.mc - 1));
-        cnn = (cache_valid && r0 < 3u && r1 < 3u && r2 < 3u) ? (r0 | (r1 << 2) | (r2 << 4)) : 0xffu;
-    };
 
 #pragma unroll 1
     for (int off = 0; off < npts; off += WAVE_STEP) {
@@ -571,6 +607,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             box(o0.seen, cx.x, cy.x, cz.x); box(o1.seen, cx.y, cy.y, cz.y); box(o2.seen, cx.z, cy.z, cz.z); box(o3.seen, cx.w, cy.w, cz.w);
         }
 
+        bool slow_step = false;   // MODE 1: this step's points carry leaf coordinates instead of positions around the cached faces
         if (MODE == 1) {
             // Are all voxels of this step between the cached faces?  u - 34 = voxel - (64 mc - 32) must lie in [0, 128).
             // Cheap test on the lane's extremes first; points that do not count (absent, non-finite) can only
@@ -585,42 +622,61 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     return o.seen && (((uint32_t)(o.u0 - 34) | (uint32_t)(o.u1 - 34) | (uint32_t)(o.u2 - 34)) >= 128u);
                 };
                 if (__ballot(outside(o0) || outside(o1) || outside(o2) || outside(o3)) != 0ull) {
-                    // Move each axis' cache to the lowest face this step needs (thresholds come from the table
-                    // the host computed), redo the step, and if lanes are still not covered (incoherent input)
-                    // give up: the host reruns the exact variant.
+                    // Where do the voxels of this step lie?  (t = u + cb - ib, lowest and highest per axis)
                     const int big = 1 << 30;
-                    int w0 = big, w1 = big, w2 = big;   // lowest voxel index per axis, t = u + cb - ib
-                    if (o0.seen) { w0 = min(w0, o0.u0); w1 = min(w1, o0.u1); w2 = min(w2, o0.u2); }
-                    if (o1.seen) { w0 = min(w0, o1.u0); w1 = min(w1, o1.u1); w2 = min(w2, o1.u2); }
-                    if (o2.seen) { w0 = min(w0, o2.u0); w1 = min(w1, o2.u1); w2 = min(w2, o2.u2); }
-                    if (o3.seen) { w0 = min(w0, o3.u0); w1 = min(w1, o3.u1); w2 = min(w2, o3.u2); }
+                    int w0 = big, w1 = big, w2 = big, v0 = -big, v1 = -big, v2 = -big;
+                    auto span = [&](const PointOut &o) {
+                        if (o.seen) {
+                            w0 = min(w0, o.u0); w1 = min(w1, o.u1); w2 = min(w2, o.u2);
+                            v0 = max(v0, o.u0); v1 = max(v1, o.u1); v2 = max(v2, o.u2);
+                        }
+                    };
+                    span(o0); span(o1); span(o2); span(o3);
                     for (int sft = 32; sft > 0; sft >>= 1) {
                         w0 = min(w0, __shfl_xor(w0, sft, 64)); w1 = min(w1, __shfl_xor(w1, sft, 64)); w2 = min(w2, __shfl_xor(w2, sft, 64));
+                        v0 = max(v0, __shfl_xor(v0, sft, 64)); v1 = max(v1, __shfl_xor(v1, sft, 64)); v2 = max(v2, __shfl_xor(v2, sft, 64));
                     }
-                    bool off_table = false;
-                    auto refill = [&](FaceCache &fc, int umin, int ib, int fb, int axis) {
-                        if (umin == big) return;
-                        const int tmin = umin + fc.cb - ib;
-                        const int m = (tmin + 32) >> 6;                 // nearest face of the lowest voxel
-                        const unsigned i = (unsigned)(m - fb);
-                        if (i + 1u >= (unsigned)FACES) { off_table = true; return; }
-                        fc.mc = m;
-                        fc.tlo = L.faces[axis * FACES + i];
-                        fc.thi = L.faces[axis * FACES + i + 1];
-                        fc.cb = ib + 64 * (m - 1) - 2;
+                    // A pair of faces covers 128 voxels.  If the step fits into that on every axis, move the
+                    // caches to the lowest face it needs (thresholds come from the table the host computed)
+                    // and redo it; if not, its points look their faces up one by one.
+                    bool fits = true, off_table = false;
+                    auto plan = [&](const FaceCache &fc, int umin, int umax, int ib, int fb, int &m) {
+                        m = fc.mc;
+                        if (umin == big) return;   // no point on this step at all
+                        const int tmin = umin + fc.cb - ib, tmax = umax + fc.cb - ib;
+                        m = (tmin + 32) >> 6;      // nearest face of the lowest voxel
+                        fits &= tmax - (64 * m - 32) < 128;
+                        fits &= (unsigned)(m - fb) + 1u < (unsigned)FACES;
                     };
-                    refill(fc0, __builtin_amdgcn_readfirstlane(w0), P.ib0, P.fb0, 0);
-                    refill(fc1, __builtin_amdgcn_readfirstlane(w1), P.ib1, P.fb1, 1);
-                    refill(fc2, __builtin_amdgcn_readfirstlane(w2), P.ib2, P.fb2, 2);
-                    update_cnn();
-                    L.nn_leaf[threadIdx.x >> 6][lane] = 0xffffffffu;   // relative leaf positions mean other leaves now
-                    o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0);
-                    o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1);
-                    o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2);
-                    o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3);
-                    if (off_table || __ballot(outside(o0) || outside(o1) || outside(o2) || outside(o3)) != 0ull) {
-                        err |= ERR_FACE_TABLE;
-                        o0.key = o1.key = o2.key = o3.key = KEY_EMPTY;
+                    int m0, m1, m2;
+                    plan(fc0, __builtin_amdgcn_readfirstlane(w0), __builtin_amdgcn_readfirstlane(v0), P.ib0, P.fb0, m0);
+                    plan(fc1, __builtin_amdgcn_readfirstlane(w1), __builtin_amdgcn_readfirstlane(v1), P.ib1, P.fb1, m1);
+                    plan(fc2, __builtin_amdgcn_readfirstlane(w2), __builtin_amdgcn_readfirstlane(v2), P.ib2, P.fb2, m2);
+                    if (fits) {
+                        auto refill = [&](FaceCache &fc, int m, int ib, int fb, int axis) {
+                            if (m == fc.mc) return;
+                            const unsigned i = (unsigned)(m - fb);
+                            fc.mc = m;
+                            fc.tlo = L.faces[axis * FACES + i];
+                            fc.thi = L.faces[axis * FACES + i + 1];
+                            fc.cb = ib + 64 * (m - 1) - 2;
+                        };
+                        refill(fc0, m0, P.ib0, P.fb0, 0);
+                        refill(fc1, m1, P.ib1, P.fb1, 1);
+                        refill(fc2, m2, P.ib2, P.fb2, 2);
+                        L.nn_leaf[threadIdx.x >> 6][lane] = 0xffffffffu;   // relative leaf positions mean other leaves now
+                        o0 = point_key<MODE>(P, fc0, fc1, fc2, cx.x, cy.x, cz.x, left > 0);
+                        o1 = point_key<MODE>(P, fc0, fc1, fc2, cx.y, cy.y, cz.y, left > 1);
+                        o2 = point_key<MODE>(P, fc0, fc1, fc2, cx.z, cy.z, cz.z, left > 2);
+                        o3 = point_key<MODE>(P, fc0, fc1, fc2, cx.w, cy.w, cz.w, left > 3);
+                    } else {
+                        slow_step = true;
+                        o0 = point_key_lookup(P, L.faces, cx.x, cy.x, cz.x, left > 0, off_table);
+                        o1 = point_key_lookup(P, L.faces, cx.y, cy.y, cz.y, left > 1, off_table);
+                        o2 = point_key_lookup(P, L.faces, cx.z, cy.z, cz.z, left > 2, off_table);
+                        o3 = point_key_lookup(P, L.faces, cx.w, cy.w, cz.w, left > 3, off_table);
+                        // beyond the table (more than 60 leaves from the first point): the host reruns the f64 variant
+                        if (__ballot(off_table) != 0ull) err |= ERR_FACE_TABLE;
                     }
                 }
             }
@@ -634,7 +690,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
 
         // ---- leaf ids ----
-        if (MODE == 1 && !(P.ablate & 64u)) {
+        if (MODE == 1 && !slow_step && !(P.ablate & 64u)) {
             // The leaf of a point is one of the 27 positions around the cached faces (nn); this wave's table
             // in LDS says which leaf that is.  A plain LDS read per point; the lookup behind it runs once
             // per position (and again after the face caches moved).
@@ -673,31 +729,20 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             // KEY_EMPTY stays all ones
             o0.key |= s0 << CELL_BITS; o1.key |= s1 << CELL_BITS; o2.key |= s2 << CELL_BITS; o3.key |= s3 << CELL_BITS;
         }
-        if (MODE != 1 && !(P.ablate & 64u)) {
-            bool mism;
-            if (MODE == 1) {
-                mism = (o0.key != KEY_EMPTY && o0.nn != cnn) || (o1.key != KEY_EMPTY && o1.nn != cnn) || (o2.key != KEY_EMPTY && o2.nn != cnn) ||
-                       (o3.key != KEY_EMPTY && o3.nn != cnn);
-            } else {
-                int mm = 0;
-                mm |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
-                mm |= o1.key != KEY_EMPTY ? (o1.l0 ^ cl0) | (o1.l1 ^ cl1) | (o1.l2 ^ cl2) : 0;
-                mm |= o2.key != KEY_EMPTY ? (o2.l0 ^ cl0) | (o2.l1 ^ cl1) | (o2.l2 ^ cl2) : 0;
-                mm |= o3.key != KEY_EMPTY ? (o3.l0 ^ cl0) | (o3.l1 ^ cl1) | (o3.l2 ^ cl2) : 0;
-                mism = mm != 0;
-            }
+        if ((MODE != 1 || slow_step) && !(P.ablate & 64u)) {
+            // the points carry leaf lattice coordinates here; one leaf and its name are cached in scalar registers
+            int mm = 0;
+            mm |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
+            mm |= o1.key != KEY_EMPTY ? (o1.l0 ^ cl0) | (o1.l1 ^ cl1) | (o1.l2 ^ cl2) : 0;
+            mm |= o2.key != KEY_EMPTY ? (o2.l0 ^ cl0) | (o2.l1 ^ cl1) | (o2.l2 ^ cl2) : 0;
+            mm |= o3.key != KEY_EMPTY ? (o3.l0 ^ cl0) | (o3.l1 ^ cl1) | (o3.l2 ^ cl2) : 0;
+            const bool mism = mm != 0;
             if (cache_valid && __ballot(mism) == 0ull) {
                 // the whole step lies in the cached leaf (the common case); KEY_EMPTY stays all ones
                 const uint32_t hi_bits = cache_id << CELL_BITS;
                 o0.key |= hi_bits; o1.key |= hi_bits; o2.key |= hi_bits; o3.key |= hi_bits;
             } else {
                 // general case: resolve the distinct leaves of this step one at a time
-                if (MODE == 1) {
-                    auto leaf_of = [&](PointOut &o) {
-                        o.l0 = fc0.mc - 1 + (int)(o.nn & 3u); o.l1 = fc1.mc - 1 + (int)((o.nn >> 2) & 3u); o.l2 = fc2.mc - 1 + (int)(o.nn >> 4);
-                    };
-                    leaf_of(o0); leaf_of(o1); leaf_of(o2); leaf_of(o3);
-                }
                 unsigned pend = (o0.key != KEY_EMPTY ? 1u : 0u) | (o1.key != KEY_EMPTY ? 2u : 0u) | (o2.key != KEY_EMPTY ? 4u : 0u) |
                                 (o3.key != KEY_EMPTY ? 8u : 0u);
                 for (;;) {
@@ -724,7 +769,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                     if ((pend & 4u) && o2.l0 == s0 && o2.l1 == s1 && o2.l2 == s2) { pend &= ~4u; o2.key = lost ? KEY_EMPTY : (o2.key | hi_bits); }
                     if ((pend & 8u) && o3.l0 == s0 && o3.l1 == s1 && o3.l2 == s2) { pend &= ~8u; o3.key = lost ? KEY_EMPTY : (o3.key | hi_bits); }
                 }
-                update_cnn();
             }
         }
 
@@ -899,6 +943,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         fkey[it] = k;
         fold[it] = ~0ull;
         if (k == KEY_EMPTY) continue;
+        if (sub == 0) atomicAdd(&L.nused, 1u);
         const uint32_t t = L.tile[e];
         const unsigned long long ea = L.a[e], eb = L.b[e], ec = L.c[e], ed = L.d[e];
         const unsigned long long cnt = ed & 0xffffull, bias = cnt * P.q_bias;
@@ -938,6 +983,11 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     __syncthreads();
     if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.seg_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
     const uint32_t nfresh = L.nfresh;
+    if (threadIdx.x == 0) {
+        // how the table fared: the host sizes the workgroups of the next call by it
+        if (L.nfallback) atomicAdd(&W.ctrl[C_FALLBACK], L.nfallback);
+        atomicMax(&W.ctrl[C_MAXLOAD], L.nused);
+    }
     if (!P.want_list) {
         // octree path: the finalize pass finds the records through the occupancy bitmaps, so the count is
         // all that is needed here, and nobody waits for this add
@@ -1449,6 +1499,10 @@ struct Workspace {
     void *head = nullptr;              // two blocks of ctrl | leaf_keys | seg_count, used by alternate passes
     size_t head_bytes = 0;             // bytes of one block
     int parity = 0;                    // block of the next pass
+    int shrink = 0;                    // log2 of how much smaller than "one workgroup per CU" the workgroups are made (sparse clouds)
+    int calm = 0;                      // calls in a row whose tables stayed less than a third full
+    size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
+    float hint_cell = 0.f;
     bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
     unsigned long long *leaf_keys = nullptr;
     unsigned long long *records = nullptr;
@@ -1560,7 +1614,16 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus <= 0) cus = 256;
     // one persistent workgroup per CU; short clouds get fewer so that every wave has at least one step,
     // very large clouds get more (sequential) workgroups: the packed table needs < 65536 points per workgroup
-    size_t nwaves = (size_t)cus * K1_WAVES;
+    // Clouds with few points per voxel fill the workgroup table (2048 voxels): the previous calls of this
+    // thread tell (ws.shrink) how much smaller the workgroups have to be for it to hold; the extra
+    // workgroups run one after the other on the same CUs.
+    if (ws.hint_cell != cellsize || n > 2 * ws.hint_n || 2 * n < ws.hint_n) {   // another kind of cloud: start over
+        ws.shrink = 0;
+        ws.calm = 0;
+    }
+    ws.hint_cell = cellsize;
+    ws.hint_n = n;
+    size_t nwaves = ((size_t)cus * K1_WAVES) << ws.shrink;
     const size_t steps_total = (n + WAVE_STEP - 1) / WAVE_STEP;
     if (nwaves > steps_total) nwaves = ((steps_total + K1_WAVES - 1) / K1_WAVES) * K1_WAVES;
     const size_t min_waves = (n + MAX_POINTS_PER_WAVE - 1) / MAX_POINTS_PER_WAVE;
@@ -1667,6 +1730,18 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
         uint32_t err = c.host_words[C_ERR];
+        {
+            // adapt the workgroup size for the next call
+            const uint32_t fallbacks = c.host_words[C_FALLBACK], maxload = c.host_words[C_MAXLOAD];
+            if ((size_t)fallbacks * 64 > n && ws.shrink < 6) {
+                ws.shrink++;
+                ws.calm = 0;
+            } else if (ws.shrink > 0 && fallbacks == 0 && maxload * 3 < (uint32_t)LTAB) {
+                if (++ws.calm >= 4) { ws.shrink--; ws.calm = 0; }
+            } else {
+                ws.calm = 0;
+            }
+        }
         const uint32_t depth = c.host_words[C_DEPTH];
         const uint32_t m = c.host_words[C_COUNT] < P.list_cap ? c.host_words[C_COUNT] : P.list_cap;
         std::shared_ptr<DeviceSoA> dst;

@@ -359,6 +359,23 @@ def test_downsample_many_leaves_in_random_order(gpu, oracle):
     check_downsample(gpu, oracle, pts, 0.0, -0.01)
 
 
+def test_downsample_wide_scanlines(gpu, oracle):
+    """A depth-camera like cloud: row-major scan lines 3 m wide, points about a voxel apart, so a wave's
+    step of 256 points spans far more than the 128 voxels one pair of cached leaf faces covers."""
+    rng = np.random.default_rng(44)
+    w, h = 640, 360
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    n = w * h
+    pts = oracle.empty(n)
+    pts['x'] = (u.ravel() * (3.0 / w) - 1.5 + rng.normal(0, 0.001, n)).astype(np.float32)
+    pts['y'] = (2.0 - v.ravel() * (2.0 / h) + rng.normal(0, 0.001, n)).astype(np.float32)
+    pts['z'] = (1.5 + 0.4 * np.sin(u.ravel() * 0.01) + rng.normal(0, 0.002, n)).astype(np.float32)
+    pts['r'], pts['g'], pts['b'] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n)
+    pts['tile'] = 1 << rng.integers(0, 3, n)
+    for cell in (0.01, 0.005, -0.01):
+        check_downsample(gpu, oracle, pts, 0.0, cell)
+
+
 def test_downsample_single_point_and_duplicates(gpu, oracle):
     pts = oracle.empty(1)
     pts['x'], pts['y'], pts['z'], pts['r'], pts['tile'] = 0.5, -0.25, 3.0, 200, 4
@@ -557,3 +574,49 @@ def test_full_size_remove_outliers(gpu, oracle, full_cloud):
     pts, cs = full_cloud
     got, exp = check_sor(gpu, oracle, pts, cs, 16, 1.0)
     assert 0 < len(got) < len(pts)
+
+
+# ---------------------------------------------------------------------------
+# threads: the reference calls filters from worker threads (net/source_synchronizer.py:17,184)
+# ---------------------------------------------------------------------------
+def test_filters_from_several_threads(gpu, oracle, synth):
+    """Every thread has its own stream and workspace; a cloud produced on one thread (its last kernel may
+    still be in flight when the call returns) is consumed on another."""
+    import threading
+    pts, cs = synth(300000)
+    exp, _ = oracle.downsample(pts, cs, 0.01)
+    exp_t1 = oracle.tilefilter(exp, 1)
+    src = make_cloud(gpu, pts, cs, 9)
+    produced, errors = [None] * 4, []
+
+    def producer(i):
+        try:
+            for _ in range(5):
+                produced[i] = gpu.cwipc_downsample(src, 0.01)
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=producer, args=(i,)) for i in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors
+    results = []
+
+    def consumer(i):
+        try:
+            results.append(gpu.cwipc_tilefilter(produced[i], 1).get_numpy_array())
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=consumer, args=((i + 1) % 4,)) for i in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors and len(results) == 4
+    for r in results:
+        assert len(r) == len(exp_t1)
+        assert (r['tile'] == 1).all() and (r['r'] == exp_t1['r']).all()
+        assert np.abs(r['x'] - exp_t1['x']).max() <= XYZ_TOL
+    # the main thread reads what worker threads produced
+    for pc in produced:
+        got = pc.get_numpy_array()
+        assert len(got) == len(exp) and (got['tile'] == exp['tile']).all()
