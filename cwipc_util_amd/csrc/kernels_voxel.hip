@@ -373,7 +373,7 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
     if (__ballot(need_or) != 0ull) {
         if (need_or) atomicOr(&L.tile[slot], r.tile);
     }
-    if (active && pending) {   // table saturated (sparse or incoherent input): straight to the global records
+    if (__builtin_expect(active && pending, 0)) {   // table saturated (sparse or incoherent input): straight to the global records
         atomicAdd(&L.nfallback, 1u);
         const uint32_t cnt = r.cr >> 16;
         const long long bias = (long long)cnt * P.q_bias;
@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                 return (uint32_t)(lo - 34) | (uint32_t)(hi - 34);
             };
             const uint32_t out = spread(o0.u0, o1.u0, o2.u0, o3.u0) | spread(o0.u1, o1.u1, o2.u1, o3.u1) | spread(o0.u2, o1.u2, o2.u2, o3.u2);
-            if (__ballot(out >= 128u) != 0ull) {
+            if (__builtin_expect(__ballot(out >= 128u) != 0ull, 0)) {
                 auto outside = [](const PointOut &o) {
                     return o.seen && (((uint32_t)(o.u0 - 34) | (uint32_t)(o.u1 - 34) | (uint32_t)(o.u2 - 34)) >= 128u);
                 };
@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             uint32_t *tab = L.nn_leaf[threadIdx.x >> 6];
             uint32_t s0 = tab[o0.nn], s1 = tab[o1.nn], s2 = tab[o2.nn], s3 = tab[o3.nn];
             const auto unknown = [](const PointOut &o, uint32_t sl) { return o.key != KEY_EMPTY && sl == 0xffffffffu; };
-            if (__ballot(unknown(o0, s0) || unknown(o1, s1) || unknown(o2, s2) || unknown(o3, s3)) != 0ull) {
+            if (__builtin_expect(__ballot(unknown(o0, s0) || unknown(o1, s1) || unknown(o2, s2) || unknown(o3, s3)) != 0ull, 0)) {
                 for (;;) {
                     const uint32_t want = unknown(o0, s0) ? o0.nn : unknown(o1, s1) ? o1.nn : unknown(o2, s2) ? o2.nn : unknown(o3, s3) ? o3.nn : 0xffu;
                     const unsigned long long need = __ballot(want != 0xffu);
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             // KEY_EMPTY stays all ones
             o0.key |= s0 << CELL_BITS; o1.key |= s1 << CELL_BITS; o2.key |= s2 << CELL_BITS; o3.key |= s3 << CELL_BITS;
         }
-        if ((MODE != 1 || slow_step) && !(P.ablate & 64u)) {
+        if ((MODE != 1 || __builtin_expect(slow_step, 0)) && !(P.ablate & 64u)) {
             // the points carry leaf lattice coordinates here; one leaf and its name are cached in scalar registers
             int mm = 0;
             mm |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
@@ -931,6 +931,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     constexpr int FLUSH_ITERS = LTAB / (K1_THREADS / 8);
     uint32_t fkey[FLUSH_ITERS];
     unsigned long long fold[FLUSH_ITERS];
+    uint32_t used = 0;   // entries in use (lanes with sub == 0 count them)
 #pragma unroll
     for (int it = 0; it < FLUSH_ITERS; it++) {
         const int e = (threadIdx.x >> 3) + it * (K1_THREADS / 8);
@@ -943,7 +944,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         fkey[it] = k;
         fold[it] = ~0ull;
         if (k == KEY_EMPTY) continue;
-        if (sub == 0) atomicAdd(&L.nused, 1u);
+        used += sub == 0 ? 1u : 0u;
         const uint32_t t = L.tile[e];
         const unsigned long long ea = L.a[e], eb = L.b[e], ec = L.c[e], ed = L.d[e];
         const unsigned long long cnt = ed & 0xffffull, bias = cnt * P.q_bias;
@@ -980,6 +981,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             else atomicAdd(&W.seg_count[sl], 1u);
         }
     }
+    for (int off = 32; off > 0; off >>= 1) used += (uint32_t)__shfl_xor((int)used, off, 64);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(&L.nused, used);
     __syncthreads();
     if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.seg_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
     const uint32_t nfresh = L.nfresh;
