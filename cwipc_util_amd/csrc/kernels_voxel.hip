@@ -51,6 +51,9 @@
 //                         what it read, so the workspace is clean for the next call.
 #include "internal.hpp"
 
+#include <atomic>
+#include <chrono>
+
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -113,6 +116,7 @@ enum {
     C_ERR = 0, C_COUNT = 1, C_DEPTH = 2, C_EVENTS = 3, C_SHIFT = 4 /* 3 x int64 */, C_MINB = 10, C_DIVB = 13,
     C_FALLBACK = 16,   // runs that found the workgroup table full and went to the global records one lane at a time
     C_MAXLOAD = 17,    // fullest workgroup table (entries)
+    C_SEQ = 31,        // host copy only: sequence number of the pass, written last (the host polls it)
     C_WORDS = 32
 };
 
@@ -1009,6 +1013,16 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 // ---------------------------------------------------------------------------
 // K2: octree bounding-box replay / global grid box
 // ---------------------------------------------------------------------------
+// Results straight into the host's pinned words, the pass's sequence number last: the host polls that
+// word instead of waiting for the stream (a blocking stream wait wakes up several microseconds late).
+__device__ __forceinline__ void publish(const uint32_t *ctrl, uint32_t *host_out, uint32_t seq) {
+    const int tid = threadIdx.x;
+    if (tid < C_SEQ) host_out[tid] = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&host_out[C_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Growth of pcl::octree::OctreePointCloud's box is sequential in input order, but a range
 // whose box lies inside the current octree box cannot trigger a growth step, so only the few
 // ranges that do are re-read point by point.
@@ -1016,7 +1030,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
                                                             const float *__restrict__ z, const float *__restrict__ bboxes,
                                                             uint32_t *__restrict__ ctrl, const unsigned long long *__restrict__ leaf_keys,
                                                             uint32_t leaf_cap, uint32_t *__restrict__ next_head, uint32_t next_head_words,
-                                                            uint32_t *__restrict__ host_out) {
+                                                            uint32_t *__restrict__ host_out, uint32_t seq) {
     // housekeeping this single workgroup has threads to spare for: zero the control block the NEXT call
     // will use (the two blocks alternate, so no memset sits in front of the next call's first kernel)
     for (uint32_t i = threadIdx.x; i < next_head_words; i += 1024) next_head[i] = 0u;
@@ -1066,7 +1080,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         }
         __syncthreads();
         // results straight into the host's pinned words: the host only waits for the stream
-        if (tid < C_WORDS) host_out[tid] = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish(ctrl, host_out, seq);
         return;
     }
 
@@ -1239,7 +1253,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         }
     }
     __syncthreads();
-    if (tid < C_WORDS) host_out[tid] = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish(ctrl, host_out, seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1502,6 +1516,7 @@ struct Workspace {
     void *head = nullptr;              // two blocks of ctrl | leaf_keys | seg_count, used by alternate passes
     size_t head_bytes = 0;             // bytes of one block
     int parity = 0;                    // block of the next pass
+    uint32_t seq = 0;                  // sequence number of the last pass (never 0 once used)
     int shrink = 0;                    // log2 of how much smaller than "one workgroup per CU" the workgroups are made (sparse clouds)
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
     size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
@@ -1677,6 +1692,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
+        const uint32_t seq = ++ws.seq ? ws.seq : ++ws.seq;
+        c.host_words[C_SEQ] = 0;
         // control words, leaf table, slice counts: this pass's block (zeroed by the previous pass's replay kernel)
         const int blk = ws.parity;
         char *head = (char *)ws.head + (size_t)blk * ws.head_bytes, *next_head = (char *)ws.head + (size_t)(1 - blk) * ws.head_bytes;
@@ -1725,11 +1742,26 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         }
         const size_t replay_lds = (leaf_split && nwaves <= REPLAY_LDS_RANGES) ? nwaves * 6 * sizeof(float) : 0;
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), replay_lds, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
-                  ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), c.host_words);
+                  ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), c.host_words, seq);
         ok = hipGetLastError() == hipSuccess;
         ws.head_clean[1 - blk] = ok;
         ws.parity = 1 - blk;
-        ok = c.sync() && ok;
+        // wait for the replay kernel's sequence number in pinned memory (a few hundred microseconds of
+        // polling at most, then the ordinary stream wait, which also reports launch failures)
+        if (ok && !profiling_enabled()) {
+            volatile uint32_t *flag = c.host_words + C_SEQ;
+            const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+            bool seen = false;
+            for (int spin = 0;; spin++) {
+                if (*flag == seq) { seen = true; break; }
+                if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;
+                __builtin_ia32_pause();
+            }
+            if (!seen) ok = c.sync() && ok;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            ok = c.sync() && ok;
+        }
         if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
         uint32_t err = c.host_words[C_ERR];
