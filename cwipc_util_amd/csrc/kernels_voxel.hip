@@ -78,11 +78,12 @@ constexpr int CELLS = GRID_DIM * GRID_DIM * GRID_DIM;   // 314432 < 2^19
 constexpr int CELL_BITS = 19;
 constexpr int BITWORDS = CELLS / 32;            // 9826 occupancy words per leaf grid (CELLS is a multiple of 32)
 constexpr uint32_t KEY_EMPTY = 0xffffffffu;
+constexpr int HIST = 256;                      // slots of the per-workgroup histogram of first touches per bitmap slice
 constexpr int LOCAL_LEAVES = 64;               // leaves a workgroup can name locally (keys carry the local slot, the flush translates)
 // the finalize pass works on slices of a leaf's occupancy bitmap
 constexpr int RANK_THREADS = 256;
-constexpr int RANK_SEGS = 8;
-constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 1229
+constexpr int RANK_SEGS = 16;                  // a few leaves hold all the work: many slices per leaf for enough workgroups
+constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 308
 constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 5
 constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
 // Offsets are summed with a per-point bias so that the packed sums never borrow.  fl(f * inv_leaf)
@@ -295,7 +296,7 @@ struct LdsTable {
     unsigned long long d[LTAB];   // count | sum r << 16 | sum g << 40
     uint32_t fresh[LTAB];         // records this workgroup touched first
     float faces[3 * FACES];
-    uint32_t htag[64], hcnt[64];  // first touches per bitmap slice of this workgroup (slice + 1, count)
+    uint32_t htag[HIST], hcnt[HIST];  // first touches per bitmap slice of this workgroup (slice + 1, count); linear probing
     uint32_t nfresh, fresh_base;
     uint32_t nfallback, nused;    // table-full fallbacks of this workgroup; entries in use (counted by the flush)
     unsigned long long leaf_tab[LOCAL_LEAVES];   // packed leaf coordinates, 0 = free; position = local leaf slot
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     if (MODE == 1) {
         for (int i = threadIdx.x; i < 3 * FACES; i += K1_THREADS) L.faces[i] = W.faces[i];
     }
-    if (threadIdx.x < 64) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
+    if (threadIdx.x < HIST) { L.htag[threadIdx.x] = 0; L.hcnt[threadIdx.x] = 0; }
     if (threadIdx.x < LOCAL_LEAVES) { L.leaf_tab[threadIdx.x] = 0ull; L.leaf_gid[threadIdx.x] = 0xffffffffu; }
     L.nn_leaf[threadIdx.x >> 6][threadIdx.x & 63] = 0xffffffffu;
     if (threadIdx.x == 0) { L.nfresh = 0; L.nfallback = 0; L.nused = 0; }
@@ -979,16 +980,24 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             const uint32_t at = atomicAdd(&L.nfresh, 1u);
             if (P.want_list) L.fresh[at] = k;
             mark_occupied(W, k);
-            const uint32_t sl = slice_of(k), hs = sl & 63u;
-            const uint32_t tag = atomicCAS(&L.htag[hs], 0u, sl + 1u);
-            if (tag == 0u || tag == sl + 1u) atomicAdd(&L.hcnt[hs], 1u);
-            else atomicAdd(&W.seg_count[sl], 1u);
+            const uint32_t sl = slice_of(k);
+            uint32_t hs = (sl * 0x9E3779B1u) >> 24;   // HIST = 2^8
+            bool counted = false;
+            for (int probe = 0; probe < 8 && !counted; probe++) {
+                const uint32_t tag = atomicCAS(&L.htag[hs], 0u, sl + 1u);
+                if (tag == 0u || tag == sl + 1u) {
+                    atomicAdd(&L.hcnt[hs], 1u);
+                    counted = true;
+                }
+                hs = (hs + 1) & (HIST - 1);
+            }
+            if (!counted) atomicAdd(&W.seg_count[sl], 1u);
         }
     }
     for (int off = 32; off > 0; off >>= 1) used += (uint32_t)__shfl_xor((int)used, off, 64);
     if ((threadIdx.x & 63) == 0 && used) atomicAdd(&L.nused, used);
     __syncthreads();
-    if (threadIdx.x < 64 && L.htag[threadIdx.x]) atomicAdd(&W.seg_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
+    if (threadIdx.x < HIST && L.htag[threadIdx.x]) atomicAdd(&W.seg_count[L.htag[threadIdx.x] - 1u], L.hcnt[threadIdx.x]);
     const uint32_t nfresh = L.nfresh;
     if (threadIdx.x == 0) {
         // how the table fared: the host sizes the workgroups of the next call by it
@@ -1422,8 +1431,11 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
         unsigned long long other;
         if (lq != 0ull && q != p && leaf_morton(W, lq, depth, other) && other < mine) {
             const uint4 *sc = reinterpret_cast<const uint4 *>(W.seg_count + (size_t)q * RANK_SEGS);
-            const uint4 s0 = sc[0], s1 = sc[1];
-            before += s0.x + s0.y + s0.z + s0.w + s1.x + s1.y + s1.z + s1.w;
+#pragma unroll
+            for (int v = 0; v < RANK_SEGS / 4; v++) {
+                const uint4 t = sc[v];
+                before += t.x + t.y + t.z + t.w;
+            }
         }
     }
     // earlier slices may already have been cleaned by their own workgroups, so their cells are
