@@ -33,6 +33,15 @@ std::shared_ptr<DeviceSoA> device_input(const char *who, cwipc_pointcloud *pc, s
     return ours->device_points();
 }
 
+// Filters that keep coordinates and order keep the first point (the octree anchor of a later
+// cwipc_downsample): no device read-back needed for it.
+void inherit_first(DeviceSoA &dst, const DeviceSoA &src) {
+    if (src.has_first && dst.npoints == src.npoints) {
+        dst.first[0] = src.first[0]; dst.first[1] = src.first[1]; dst.first[2] = src.first[2];
+        dst.has_first = true;
+    }
+}
+
 cwipc_pointcloud *wrap(std::shared_ptr<DeviceSoA> planes, uint64_t timestamp, float cellsize) {
     if (!planes) return nullptr;
     auto *rv = new cwipc_hip_pointcloud();
@@ -130,6 +139,7 @@ extern "C" cwipc_pointcloud *cwipc_tilemap(cwipc_pointcloud *pc, uint8_t map[256
     if (ok) k::map_tile(*src, *dst, (const uint8_t *)c.dev_words, c.stream);
     ok = c.sync() && ok;
     if (!ok) return nullptr;
+    inherit_first(*dst, *src);
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
@@ -145,6 +155,7 @@ extern "C" cwipc_pointcloud *cwipc_colormap(cwipc_pointcloud *pc, uint32_t clear
     if (!dst) return nullptr;
     k::map_color_bits(*src, *dst, clearBits, setBits, c.stream);
     if (!c.sync()) return nullptr;
+    inherit_first(*dst, *src);
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
@@ -174,6 +185,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double wei
     ok = c.sync() && ok;
     pool_free(dev_table);
     if (!ok) return nullptr;
+    inherit_first(*dst, *src);
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 

@@ -1614,13 +1614,17 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
     return true;
 }
 
-// The first point of a cloud the host has not seen (a filter result): three 4-byte reads, once per cloud.
+// The first point of a cloud the host has not seen (a filter result), once per cloud: one lane writes
+// it into the pinned words (one launch instead of three copy operations).
+__global__ void first_point_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, float *__restrict__ host_out) {
+    host_out[0] = x[0]; host_out[1] = y[0]; host_out[2] = z[0];
+}
+
 bool fetch_first_point(const DeviceSoA &src, ThreadCtx &c) {
     if (src.has_first) return true;
     float *h = (float *)c.host_words;
-    bool ok = hipMemcpyAsync(h, src.x(), 4, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
-              hipMemcpyAsync(h + 1, src.y(), 4, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
-              hipMemcpyAsync(h + 2, src.z(), 4, hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    hipLaunchKernelGGL(first_point_kernel, dim3(1), dim3(1), 0, c.stream, src.x(), src.y(), src.z(), h);
+    bool ok = hipGetLastError() == hipSuccess;
     ok = c.sync() && ok;
     if (!ok) return hip_failed(hipGetLastError(), "fetch of the first point", __FILE__, __LINE__);
     src.first[0] = h[0]; src.first[1] = h[1]; src.first[2] = h[2];
