@@ -27,7 +27,7 @@ namespace cwipc_amd {
 namespace {
 
 constexpr int BLK = 256;
-constexpr size_t MAX_CELLS = (size_t)1 << 24;
+constexpr size_t MAX_CELLS = (size_t)1 << 27;   // dense grid cells at most (three 4-byte arrays of this length); a call uses 8 per point at most
 
 struct Grid {
     float mn[3];
@@ -376,8 +376,8 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     double h_min = maxext / 1024.0;
     while (cells_of(make_grid(h_min)) > probe_cells) h_min *= 1.25;
 
-    uint32_t *counts = (uint32_t *)pool_alloc(MAX_CELLS * sizeof(uint32_t) + 256);
-    uint32_t *fill = (uint32_t *)pool_alloc(MAX_CELLS * sizeof(uint32_t));
+    uint32_t *counts = (uint32_t *)pool_alloc(probe_cells * sizeof(uint32_t) + 256);
+    uint32_t *fill = (uint32_t *)pool_alloc(probe_cells * sizeof(uint32_t));
     uint32_t *cell_id = (uint32_t *)pool_alloc(n * sizeof(uint32_t));
     float4 *sorted = (float4 *)pool_alloc(n * sizeof(float4));
     void *scan_tmp = nullptr;
@@ -388,7 +388,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     //    (surface-like data: points per cell grow with h^2)
     Grid g = make_grid(h_min);
     size_t ncells = cells_of(g);
-    uint32_t *occ_dev = counts + MAX_CELLS;
+    uint32_t *occ_dev = counts + probe_cells;
     ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess &&
          hipMemsetAsync(occ_dev, 0, sizeof(uint32_t), c.stream) == hipSuccess;
     if (ok) {
