@@ -1266,10 +1266,9 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
 }
 
 // ---------------------------------------------------------------------------
-// K3: output-order keys
+// K3: output-order keys of the plain grid's sort path (index spaces beyond 2^28 cells)
 // ---------------------------------------------------------------------------
-// positive cellsize: [ Morton code of the leaf's final octree key | k | j | i inside the leaf ]
-// negative cellsize: pcl::VoxelGrid's idx = i + j*div_x + k*div_x*div_y
+// pcl::VoxelGrid's idx = i + j*div_x + k*div_x*div_y
 __global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWork W, uint32_t m, unsigned long long *__restrict__ sort_keys,
                                                             uint32_t *__restrict__ sort_vals) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -1278,34 +1277,10 @@ __global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWor
     const uint32_t cell = key & ((1u << CELL_BITS) - 1), leaf_id = key >> CELL_BITS;
     const int c[3] = {(int)(cell % GRID_DIM), (int)((cell / GRID_DIM) % GRID_DIM), (int)(cell / (GRID_DIM * GRID_DIM))};
     const unsigned long long lp = W.leaf_keys[leaf_id];
-    unsigned long long sk;
-    if (!P.leaf_split) {
-        long long d[3];
-        for (int a = 0; a < 3; a++) d[a] = (long long)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2) - (long long)(int)W.ctrl[C_MINB + a];
-        const long long dx = (int)W.ctrl[C_DIVB], dy = (int)W.ctrl[C_DIVB + 1];
-        sk = (unsigned long long)(d[0] + d[1] * dx + d[2] * dx * dy);
-    } else {
-        const int depth = (int)W.ctrl[C_DEPTH];
-        long long lk[3];
-        bool bad = depth > 14;
-        for (int a = 0; a < 3; a++) {
-            const long long shift = (long long)(((unsigned long long)W.ctrl[C_SHIFT + 2 * a + 1] << 32) | W.ctrl[C_SHIFT + 2 * a]);
-            lk[a] = (long long)unpack_leaf(lp, a) + shift;
-            if (lk[a] < 0 || lk[a] >= ((long long)1 << depth)) bad = true;
-        }
-        if (bad) {
-            atomicOr(&W.ctrl[C_ERR], depth > 14 ? ERR_DEPTH : ERR_LEAF_RANGE);
-            sk = ~0ull;
-        } else {
-            unsigned long long morton = 0;
-            for (int b = depth - 1; b >= 0; b--) {
-                morton = (morton << 3) | (((unsigned long long)(lk[0] >> b) & 1) << 2) | (((unsigned long long)(lk[1] >> b) & 1) << 1) |
-                         ((unsigned long long)(lk[2] >> b) & 1);
-            }
-            sk = (morton << 21) | ((unsigned long long)c[2] << 14) | ((unsigned long long)c[1] << 7) | (unsigned long long)c[0];
-        }
-    }
-    sort_keys[r] = sk;
+    long long d[3];
+    for (int a = 0; a < 3; a++) d[a] = (long long)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2) - (long long)(int)W.ctrl[C_MINB + a];
+    const long long dx = (int)W.ctrl[C_DIVB], dy = (int)W.ctrl[C_DIVB + 1];
+    sort_keys[r] = (unsigned long long)(d[0] + d[1] * dx + d[2] * dx * dy);
     sort_vals[r] = key;
 }
 
@@ -1496,6 +1471,113 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
     }
 }
 
+// ---------------------------------------------------------------------------
+// Sort-free output order for the plain grid: pcl::VoxelGrid emits voxels by ascending
+// idx = i + j * div_x + k * div_x * div_y.  A bitmap over that index space (it has at most 2^31
+// cells by VoxelGrid's own rule; the bitmap path takes up to 2^28) turns the order into popcount ranks.
+// ---------------------------------------------------------------------------
+constexpr uint32_t GRID_BITMAP_MAX_CELLS = 1u << 28;
+constexpr int GB_WORDS_PER_BLOCK = 1024;
+
+__device__ __forceinline__ uint32_t voxelgrid_index(const VoxParams &P, const VoxWork &W, uint32_t key) {
+    const uint32_t cell = key & ((1u << CELL_BITS) - 1), leaf_id = key >> CELL_BITS;
+    const int c[3] = {(int)(cell % GRID_DIM), (int)((cell / GRID_DIM) % GRID_DIM), (int)(cell / (GRID_DIM * GRID_DIM))};
+    const unsigned long long lp = W.leaf_keys[leaf_id];
+    long long d[3];
+    for (int a = 0; a < 3; a++) d[a] = (long long)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2) - (long long)(int)W.ctrl[C_MINB + a];
+    const long long dx = (int)W.ctrl[C_DIVB], dy = (int)W.ctrl[C_DIVB + 1];
+    return (uint32_t)(d[0] + d[1] * dx + d[2] * dx * dy);
+}
+
+// one bit per touched record; its index is kept for the passes that follow
+__global__ void __launch_bounds__(256) grid_mark_kernel(VoxParams P, VoxWork W, uint32_t m, uint32_t *__restrict__ gbits, uint32_t *__restrict__ gidx) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const uint32_t idx = voxelgrid_index(P, W, W.occupied[r]);
+    gidx[r] = idx;
+    atomicOr(&gbits[idx >> 5], 1u << (idx & 31u));
+}
+
+// per block of 1024 bitmap words: set bits before each word (inside the block), set bits of the block
+__global__ void __launch_bounds__(256) grid_block_kernel(const uint32_t *__restrict__ gbits, uint32_t nwords, uint32_t *__restrict__ word_prefix,
+                                                        uint32_t *__restrict__ block_sum) {
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t w0 = blockIdx.x * GB_WORDS_PER_BLOCK + threadIdx.x * 4;
+    uint32_t c[4];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        c[i] = w0 + i < nwords ? __popc(gbits[w0 + i]) : 0u;
+        mine += c[i];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - mine, total = 0;
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += wave_tot[w];
+        total += wave_tot[w];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (w0 + i < nwords) word_prefix[w0 + i] = before;
+        before += c[i];
+    }
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+
+// exclusive scan of the block sums, one workgroup
+__global__ void __launch_bounds__(1024) grid_blockscan_kernel(uint32_t *__restrict__ block_sum, uint32_t nblocks) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sum[i] : 0;
+        uint32_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < wave; w++) wbase += wave_tot[w];
+        const uint32_t c = carry;
+        if (i < nblocks) block_sum[i] = c + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wbase + inc;
+        __syncthreads();
+    }
+}
+
+// rank of the record's bit = its output position; emit, clean the record and the leaf bitmap bit
+__global__ void __launch_bounds__(256) grid_emit_kernel(VoxParams P, VoxWork W, uint32_t m, const uint32_t *__restrict__ gidx,
+                                                       const uint32_t *__restrict__ gbits, const uint32_t *__restrict__ word_prefix,
+                                                       const uint32_t *__restrict__ block_sum, float *__restrict__ ox, float *__restrict__ oy,
+                                                       float *__restrict__ oz, uint32_t *__restrict__ ow) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const uint32_t key = W.occupied[r], idx = gidx[r], w = idx >> 5;
+    const uint32_t rank = block_sum[w / GB_WORDS_PER_BLOCK] + word_prefix[w] + __popc(gbits[w] & ((1u << (idx & 31u)) - 1u));
+    if (rank < m) emit_record(P, W, W.leaf_keys[key >> CELL_BITS], key, rank, ox, oy, oz, ow);
+    const uint32_t bit_cell = key & ((1u << CELL_BITS) - 1);
+    atomicAnd(&W.bitmaps[(size_t)(key >> CELL_BITS) * BITWORDS + (bit_cell >> 5)], ~(1u << (bit_cell & 31u)));
+}
+
+// the index bitmap is left zeroed for the next call (after every rank has been read)
+__global__ void __launch_bounds__(256) grid_unmark_kernel(uint32_t m, const uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbits) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < m) gbits[gidx[r] >> 5] = 0u;
+}
+
 // Error path of the octree variant (no list of touched records there): zero every record whose bit is
 // set, and the bitmaps.  Same launch shape as rank_emit_kernel.
 __global__ void __launch_bounds__(RANK_THREADS) clean_by_bitmap_kernel(VoxWork W) {
@@ -1538,6 +1620,9 @@ struct Workspace {
     unsigned long long *records = nullptr;
     uint32_t *occupied = nullptr;
     uint32_t *order = nullptr;         // records in output order (finalize pass), list_cap entries
+    uint32_t *gbits = nullptr;         // plain grid: bitmap over the VoxelGrid index space, its per-word and per-block prefixes
+    uint32_t *gprefix = nullptr, *gblock = nullptr;
+    size_t gwords_cap = 0;
     float *bboxes = nullptr;
     uint32_t *ctrl = nullptr;
     uint32_t *bitmaps = nullptr;
@@ -1551,6 +1636,10 @@ struct Workspace {
         if (records) (void)hipFree(records);
         if (occupied) (void)hipFree(occupied);
         if (order) (void)hipFree(order);
+        if (gbits) (void)hipFree(gbits);
+        if (gprefix) (void)hipFree(gprefix);
+        if (gblock) (void)hipFree(gblock);
+        gbits = gprefix = gblock = nullptr; gwords_cap = 0;
         if (bboxes) (void)hipFree(bboxes);
         if (faces) (void)hipFree(faces);
         if (bitmaps) (void)hipFree(bitmaps);
@@ -1793,7 +1882,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 ws.calm = 0;
             }
         }
-        const uint32_t depth = c.host_words[C_DEPTH];
         const uint32_t m = c.host_words[C_COUNT] < P.list_cap ? c.host_words[C_COUNT] : P.list_cap;
         std::shared_ptr<DeviceSoA> dst;
         unsigned long long *keys_in = nullptr, *keys_out = nullptr;
@@ -1817,7 +1905,42 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 ranked = true;
             }
         }
+        bool grid_ranked = false;
         if (!err && m && !leaf_split) {
+            // plain grid, the usual case: output order from a bitmap over the VoxelGrid index space, no sort;
+            // like the octree variant the call returns with these passes in flight
+            const unsigned long long cells = (unsigned long long)c.host_words[C_DIVB] * c.host_words[C_DIVB + 1] * c.host_words[C_DIVB + 2];
+            unsigned long long bitmap_max = GRID_BITMAP_MAX_CELLS;
+            if (const char *e = getenv("CWIPC_GRID_BITMAP_MAX")) bitmap_max = strtoull(e, nullptr, 10);   // test knob: force the sort path
+            if (cells <= bitmap_max) {
+                const uint32_t nwords = (uint32_t)((cells + 31) / 32), nblk = (nwords + GB_WORDS_PER_BLOCK - 1) / GB_WORDS_PER_BLOCK;
+                bool ready = true;
+                if (ws.gwords_cap < nwords) {
+                    if (ws.gbits) (void)hipFree(ws.gbits);
+                    if (ws.gprefix) (void)hipFree(ws.gprefix);
+                    if (ws.gblock) (void)hipFree(ws.gblock);
+                    ws.gbits = ws.gprefix = ws.gblock = nullptr; ws.gwords_cap = 0;
+                    const size_t cap = std::max<size_t>((size_t)nwords * 2, (size_t)1 << 16);
+                    ready = hipMalloc((void **)&ws.gbits, cap * 4) == hipSuccess && hipMalloc((void **)&ws.gprefix, cap * 4) == hipSuccess &&
+                            hipMalloc((void **)&ws.gblock, (cap / GB_WORDS_PER_BLOCK + 2) * 4) == hipSuccess &&
+                            hipMemsetAsync(ws.gbits, 0, cap * 4, c.stream) == hipSuccess;
+                    if (ready) ws.gwords_cap = cap; else (void)hipGetLastError();
+                }
+                dst = ready ? soa_alloc(m) : nullptr;
+                if (dst) {
+                    CW_LAUNCH("grid_mark", grid_mark_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, ws.gbits, ws.order);
+                    CW_LAUNCH("grid_block", grid_block_kernel, dim3(nblk), dim3(256), 0, c.stream, ws.gbits, nwords, ws.gprefix, ws.gblock);
+                    CW_LAUNCH("grid_blockscan", grid_blockscan_kernel, dim3(1), dim3(1024), 0, c.stream, ws.gblock, nblk);
+                    CW_LAUNCH("grid_emit", grid_emit_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, ws.order, ws.gbits, ws.gprefix, ws.gblock,
+                              dst->x(), dst->y(), dst->z(), dst->rgbt());
+                    CW_LAUNCH("grid_unmark", grid_unmark_kernel, dim3(mgrid), dim3(256), 0, c.stream, m, ws.order, ws.gbits);
+                    dst->mark_pending(c.stream);
+                    grid_ranked = true;
+                }
+            }
+        }
+        if (!err && m && !leaf_split && !grid_ranked) {
+            // index spaces beyond 2^28 cells: sort the touched records by index
             dst = soa_alloc(m);
             keys_in = (unsigned long long *)pool_alloc((size_t)m * 8 * 2);
             vals_in = (uint32_t *)pool_alloc((size_t)m * 4 * 2);
@@ -1828,8 +1951,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 vals_out = vals_in + m;
                 CW_LAUNCH("make_sort_keys", make_sort_keys_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, keys_in, vals_in);
                 // only the bits that can be set take part in the sort
-                unsigned end_bit = leaf_split ? 21 + 3 * depth : 32;
-                if (end_bit > 64) end_bit = 64;
+                const unsigned end_bit = 32;   // idx < 2^31
                 size_t tmp_bytes = 0;
                 hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)m, 0u, end_bit, c.stream);
                 if (e == hipSuccess) {
@@ -1852,7 +1974,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
             ok = c.sync() && ok;
         }
-        if (!leaf_split && m) {
+        if (!leaf_split && m && !grid_ranked) {
             // emit (or, on error, only clean): the records must be left zeroed either way
             const int emit = (!err && dst) ? 1 : 0;
             CW_LAUNCH("emit_and_clean", emit_and_clean_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, vals_out, emit ? dst->x() : nullptr,

@@ -376,6 +376,16 @@ def test_downsample_wide_scanlines(gpu, oracle):
         check_downsample(gpu, oracle, pts, 0.0, cell)
 
 
+def test_downsample_plain_grid_sort_path(gpu, oracle, synth, monkeypatch):
+    """The plain grid orders its output through a bitmap over the VoxelGrid index space; index spaces
+    beyond 2^28 cells are sorted instead.  Force that path (it needs tens of GB of bricks otherwise)."""
+    pts, cs = synth(300000)
+    a, _ = check_downsample(gpu, oracle, pts, cs, -0.01)
+    monkeypatch.setenv("CWIPC_GRID_BITMAP_MAX", "0")
+    b, _ = check_downsample(gpu, oracle, pts, cs, -0.01)
+    assert same(a, b)
+
+
 def test_downsample_single_point_and_duplicates(gpu, oracle):
     pts = oracle.empty(1)
     pts['x'], pts['y'], pts['z'], pts['r'], pts['tile'] = 0.5, -0.25, 3.0, 200, 4
