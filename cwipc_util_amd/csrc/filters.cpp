@@ -159,6 +159,64 @@ extern "C" cwipc_pointcloud *cwipc_colormap(cwipc_pointcloud *pc, uint32_t clear
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
+// reference python/cwipc/registration/util.py:295-309 (cwipc_transform: numpy R @ p + t in float64, stored as float32)
+extern "C" cwipc_pointcloud *cwipc_hip_transform(cwipc_pointcloud *pc, const double *matrix4x4) {
+    if (pc == nullptr || matrix4x4 == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_transform", pc, keep);
+    if (!src) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_alloc(src->npoints);
+    if (!dst) return nullptr;
+    double m[12];
+    for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++) m[r * 4 + col] = matrix4x4[r * 4 + col];
+    k::map_affine(*src, *dst, m, 0, c.stream);
+    if (!c.sync()) return nullptr;
+    return wrap(dst, pc->timestamp(), pc->cellsize());
+}
+
+// reference python/cwipc/filters/transform.py:38-52 (TransformFilter: (p + offset) * scale in Python floats; cellsize * scale)
+extern "C" cwipc_pointcloud *cwipc_hip_offset_scale(cwipc_pointcloud *pc, double x, double y, double z, double scale) {
+    if (pc == nullptr) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_offset_scale", pc, keep);
+    if (!src) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_alloc(src->npoints);
+    if (!dst) return nullptr;
+    double m[12] = {scale, 0, 0, x, 0, 0, 0, y, 0, 0, 0, z};
+    k::map_affine(*src, *dst, m, 1, c.stream);
+    if (!c.sync()) return nullptr;
+    return wrap(dst, pc->timestamp(), (float)((double)pc->cellsize() * scale));
+}
+
+// reference python/cwipc/registration/util.py:285-293 (get_tiles_used): used[t] = 1 for every tile value that occurs
+extern "C" int cwipc_hip_tiles_used(cwipc_pointcloud *pc, uint8_t *used256) {
+    if (pc == nullptr || used256 == nullptr) return -1;
+    memset(used256, 0, 256);
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_tiles_used", pc, keep);
+    if (!src) return -1;
+    if (src->npoints == 0) return 0;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return -1;
+    uint32_t *dev = (uint32_t *)c.dev_words;
+    bool ok = hipMemsetAsync(dev, 0, 32, c.stream) == hipSuccess;
+    if (ok) k::tiles_used(*src, dev, c.stream);
+    ok = ok && hipMemcpyAsync(c.host_words, dev, 32, hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+    ok = c.sync() && ok;
+    if (!ok) return -1;
+    int count = 0;
+    for (int t = 0; t < 256; t++) {
+        used256[t] = (c.host_words[t >> 5] >> (t & 31)) & 1u;
+        count += used256[t];
+    }
+    return count;
+}
+
 // reference python/cwipc/filters/colorize.py:100-119
 extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid) {
     if (pc == nullptr || lut == nullptr || valid == nullptr) return nullptr;

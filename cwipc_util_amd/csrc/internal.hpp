@@ -244,6 +244,10 @@ void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *b
 // Per-point maps on the rgbt word (x,y,z copied).
 void map_tile(const DeviceSoA &src, const DeviceSoA &dst, const uint8_t *dev_map256, hipStream_t s);
 void map_color_bits(const DeviceSoA &src, const DeviceSoA &dst, uint32_t clearBits, uint32_t setBits, hipStream_t s);
+// mode 0: p' = R p + t with m = rows of [R | t]; mode 1: p' = (p + (m[3], m[7], m[11])) * m[0]; f64 arithmetic, one rounding to fp32
+void map_affine(const DeviceSoA &src, const DeviceSoA &dst, const double m[12], int mode, hipStream_t s);
+// ORs the set of tile values that occur into 8 device words
+void tiles_used(const DeviceSoA &src, uint32_t *dev_bits8, hipStream_t s);
 // colorize: dev_table = 256 entries of {double cw[3]; double valid;} followed by 256 doubles old/255.0, then (1-w).
 void map_colorize(const DeviceSoA &src, const DeviceSoA &dst, const double *dev_table, hipStream_t s);
 

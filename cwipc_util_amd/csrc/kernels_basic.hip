@@ -384,6 +384,72 @@ void map_colorize(const DeviceSoA &src, const DeviceSoA &dst, const double *dev_
 }
 
 // ---------------------------------------------------------------------------
+// geometry maps: affine transform, offset + scale (both in f64, one rounding to fp32)
+// ---------------------------------------------------------------------------
+struct AffineArgs {
+    double m[12];   // rows of the 3x4 matrix [R | t]
+    int mode;       // 0: R p + t  (reference python/cwipc/registration/util.py:295-309); 1: (p + t) * m[0]  (filters/transform.py:45-48)
+};
+
+__global__ void __launch_bounds__(BLOCK) affine_kernel(AffineArgs a, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                      const uint32_t *__restrict__ rgbt, float *__restrict__ ox, float *__restrict__ oy,
+                                                      float *__restrict__ oz, uint32_t *__restrict__ ow, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const double px = (double)x[i], py = (double)y[i], pz = (double)z[i];
+        double rx, ry, rz;
+        if (a.mode == 0) {
+            // three products summed in index order, then the translation: separately rounded f64 operations
+            rx = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[0], px), __dmul_rn(a.m[1], py)), __dmul_rn(a.m[2], pz)), a.m[3]);
+            ry = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[4], px), __dmul_rn(a.m[5], py)), __dmul_rn(a.m[6], pz)), a.m[7]);
+            rz = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[8], px), __dmul_rn(a.m[9], py)), __dmul_rn(a.m[10], pz)), a.m[11]);
+        } else {
+            rx = __dmul_rn(__dadd_rn(px, a.m[3]), a.m[0]);
+            ry = __dmul_rn(__dadd_rn(py, a.m[7]), a.m[0]);
+            rz = __dmul_rn(__dadd_rn(pz, a.m[11]), a.m[0]);
+        }
+        ox[i] = (float)rx; oy[i] = (float)ry; oz[i] = (float)rz;
+        ow[i] = rgbt[i];
+    }
+}
+
+void map_affine(const DeviceSoA &src, const DeviceSoA &dst, const double m[12], int mode, hipStream_t s) {
+    const size_t n = src.npoints;
+    if (!n) return;
+    AffineArgs a;
+    for (int i = 0; i < 12; i++) a.m[i] = m[i];
+    a.mode = mode;
+    CW_LAUNCH("map_affine", affine_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, a, src.x(), src.y(), src.z(), src.rgbt(), dst.x(), dst.y(), dst.z(),
+              dst.rgbt(), n);
+}
+
+// which tile values occur: 256-bit set (8 words)
+__global__ void __launch_bounds__(BLOCK) tiles_used_kernel(const uint32_t *__restrict__ rgbt, size_t n, uint32_t *__restrict__ bits) {
+    __shared__ uint32_t local[8];
+    if (threadIdx.x < 8) local[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const uint32_t t = rgbt[i] >> 24;
+#pragma unroll
+        for (int w = 0; w < 8; w++) mine[w] |= (t >> 5) == (uint32_t)w ? 1u << (t & 31u) : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        uint32_t v = mine[w];
+        for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicOr(&local[w], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && local[threadIdx.x]) atomicOr(&bits[threadIdx.x], local[threadIdx.x]);
+}
+
+void tiles_used(const DeviceSoA &src, uint32_t *dev_bits8, hipStream_t s) {
+    const size_t n = src.npoints;
+    if (!n) return;
+    CW_LAUNCH("tiles_used", tiles_used_kernel, dim3(grid_for(n, BLOCK) > 1024 ? 1024 : grid_for(n, BLOCK)), dim3(BLOCK), 0, s, src.rgbt(), n, dev_bits8);
+}
+
+// ---------------------------------------------------------------------------
 // join: plane-wise concatenation
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) join_copy_kernel(JoinPart part, float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,

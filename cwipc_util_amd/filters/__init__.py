@@ -9,9 +9,9 @@ import ast
 from typing import cast
 
 from .abstract import cwipc_abstract_filter
-from . import passthrough, voxelize, crop, remove_outliers, colorize
+from . import passthrough, voxelize, crop, remove_outliers, colorize, transform
 
-all_filters = [passthrough, voxelize, crop, remove_outliers, colorize]
+all_filters = [passthrough, voxelize, crop, remove_outliers, colorize, transform]
 _by_name = {m.CustomFilter.filtername: m for m in all_filters}
 
 

@@ -41,6 +41,7 @@ __all__ = [
     # MI355X extensions (no reference counterpart)
     'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked',
     'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_copy_device_aos',
+    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used',
 ]
 
 # reference util.py:86, 346, 348
@@ -205,6 +206,9 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_colorize': ([cwipc_pointcloud_p, _c.c_double, _c.c_void_p, _c.c_void_p], cwipc_pointcloud_p),
     'cwipc_hip_join_multi': ([_c.POINTER(cwipc_pointcloud_p), _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_tilefilter_masked': ([cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
+    'cwipc_hip_transform': ([cwipc_pointcloud_p, _c.POINTER(_c.c_double)], cwipc_pointcloud_p),
+    'cwipc_hip_offset_scale': ([cwipc_pointcloud_p, _c.c_double, _c.c_double, _c.c_double, _c.c_double], cwipc_pointcloud_p),
+    'cwipc_hip_tiles_used': ([cwipc_pointcloud_p, _c.POINTER(_c.c_ubyte)], _c.c_int),
     'cwipc_hip_knn_mean_dist': ([cwipc_pointcloud_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_double), _c.c_float], _c.c_int),
     'cwipc_hip_profile_enable': ([_c.c_int], None),
     'cwipc_hip_profile_reset': ([], None),
@@ -824,6 +828,32 @@ def cwipc_hip_colorize(pc: cwipc_pointcloud_wrapper, weight: float, lut: numpy.n
 def cwipc_tilefilter_masked(pc: cwipc_pointcloud_wrapper, mask: int) -> cwipc_pointcloud_wrapper:
     """Points whose tile number ANDed with mask is non-zero (reference python/cwipc/registration/util.py:98-112)."""
     return _wrap_filter_result('cwipc_tilefilter_masked', cwipc_util_dll_load().cwipc_hip_tilefilter_masked(pc.as_cwipc_p(), mask))
+
+
+def cwipc_transform(pc: cwipc_pointcloud_wrapper, transform: Any) -> cwipc_pointcloud_wrapper:
+    """Apply a 4x4 affine transformation (reference python/cwipc/registration/util.py:295-309: numpy
+    `rot @ p + t` in float64, stored as float32).  Runs on the GPU, the cloud stays device-resident."""
+    m = numpy.ascontiguousarray(numpy.asarray(transform, dtype=numpy.float64))
+    if m.shape != (4, 4):
+        raise ValueError("cwipc_transform: transform must be a 4x4 matrix")
+    rv = cwipc_util_dll_load().cwipc_hip_transform(pc.as_cwipc_p(), m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return _wrap_filter_result('cwipc_transform', rv)
+
+
+def cwipc_offset_scale(pc: cwipc_pointcloud_wrapper, x: float, y: float, z: float, scale: float) -> cwipc_pointcloud_wrapper:
+    """(p + (x, y, z)) * scale for every point, cellsize * scale (the loop of the reference's TransformFilter,
+    python/cwipc/filters/transform.py:38-52, in the same float64 arithmetic)."""
+    rv = cwipc_util_dll_load().cwipc_hip_offset_scale(pc.as_cwipc_p(), float(x), float(y), float(z), float(scale))
+    return _wrap_filter_result('cwipc_offset_scale', rv)
+
+
+def get_tiles_used(pc: cwipc_pointcloud_wrapper) -> List[int]:
+    """Sorted list of the tile numbers that occur (reference python/cwipc/registration/util.py:285-293), without downloading the cloud."""
+    used = (ctypes.c_ubyte * 256)()
+    rc = cwipc_util_dll_load().cwipc_hip_tiles_used(pc.as_cwipc_p(), used)
+    if rc < 0:
+        raise CwipcError("get_tiles_used failed")
+    return [t for t in range(256) if used[t]]
 
 
 def cwipc_hip_knn_mean_dist(pc: cwipc_pointcloud_wrapper, kNeighbors: int, stddevMulThresh: float = 1.0) -> Tuple[numpy.ndarray, float]:

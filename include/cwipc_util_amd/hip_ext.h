@@ -45,6 +45,13 @@ _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_aos(const void *dev_p
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid);
 /* cwipc_join_multi (reference python/cwipc/util.py:1330-1332): same result as the left fold of cwipc_join, one pass. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int npc);
+/* p' = R p + t for a row-major 4x4 matrix (last row ignored), in f64, stored as float: what the reference's
+ * cwipc_transform does through numpy (python/cwipc/registration/util.py:295-309). */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_transform(cwipc_pointcloud *pc, const double *matrix4x4);
+/* p' = (p + (x, y, z)) * scale in f64, cellsize * scale: the reference's TransformFilter loop (python/cwipc/filters/transform.py:38-52). */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_offset_scale(cwipc_pointcloud *pc, double x, double y, double z, double scale);
+/* used256[t] = 1 for every tile value t that occurs (python/cwipc/registration/util.py:285-293, get_tiles_used); returns how many, -1 on error. */
+_CWIPC_UTIL_EXPORT int cwipc_hip_tiles_used(cwipc_pointcloud *pc, uint8_t *used256);
 /* cwipc_tilefilter_masked (reference python/cwipc/registration/util.py:98-112): keep points with (tile & mask) != 0. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_tilefilter_masked(cwipc_pointcloud *pc, int mask);
 

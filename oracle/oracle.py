@@ -193,3 +193,34 @@ def knn_mean_dist(pts: np.ndarray, k: int) -> np.ndarray:
     if rc != 0:
         raise OracleError("knn_mean_dist failed")
     return md[:len(pts)]
+
+
+# ---------------------------------------------------------------------------
+# numpy-side helpers of the reference that are really per-point kernels
+# ---------------------------------------------------------------------------
+def transform(pts: np.ndarray, matrix4x4) -> np.ndarray:
+    """reference python/cwipc/registration/util.py:295-309 (cwipc_transform): the same numpy operations,
+    float32 columns, float64 rotation and translation, the result stored back as float32."""
+    pts = _pts(pts)
+    m = np.asarray(matrix4x4, dtype=np.float64)
+    xyz = np.stack([pts['x'], pts['y'], pts['z']], axis=1)          # float32 N x 3, as get_numpy_matrix builds it
+    rotmat, transvec = m[:3, :3], m[:3, 3].transpose()
+    moved = (rotmat @ xyz.transpose()).transpose() + transvec         # float64
+    out = pts.copy()
+    out['x'], out['y'], out['z'] = moved[:, 0].astype(np.float32), moved[:, 1].astype(np.float32), moved[:, 2].astype(np.float32)
+    return out
+
+
+def offset_scale(pts: np.ndarray, x: float, y: float, z: float, scale: float) -> np.ndarray:
+    """reference python/cwipc/filters/transform.py:38-52 (TransformFilter.filter): p.x = (p.x + x) * scale in
+    Python floats (float64), stored into a c_float."""
+    pts = _pts(pts)
+    out = pts.copy()
+    for f, o in (('x', x), ('y', y), ('z', z)):
+        out[f] = ((pts[f].astype(np.float64) + float(o)) * float(scale)).astype(np.float32)
+    return out
+
+
+def tiles_used(pts: np.ndarray):
+    """reference python/cwipc/registration/util.py:285-293 (get_tiles_used)."""
+    return sorted(np.unique(_pts(pts)['tile']).tolist())
