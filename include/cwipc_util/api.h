@@ -271,7 +271,14 @@ _CWIPC_UTIL_EXPORT size_t cwipc_metadata_size(cwipc_metadata *collection, int id
 
 /* ---- generators (reference api.h:1020-1050, 1143) ---- */
 _CWIPC_UTIL_EXPORT cwipc_activesource *cwipc_synthetic(int fps, int npoints, char **errorMessage, uint64_t apiVersion);
-_CWIPC_UTIL_EXPORT cwipc_activesource *cwipc_capturer(const char *configFilename, char **errorMessage, uint64_t apiVersion); /* hardware capture: out of scope, fails with a message */
+/* cwipc_capturer dispatches on the "type" of the camera configuration ("auto", a .json file name or a JSON literal)
+ * to the factory a camera plugin registered (reference src/cwipc_capturer.cpp:31-150).  No camera plugin is part of
+ * this library: without a registered plugin the call fails with a message. */
+_CWIPC_UTIL_EXPORT cwipc_activesource *cwipc_capturer(const char *configFilename, char **errorMessage, uint64_t apiVersion);
+/* Registration hook of the camera plugins (reference include/cwipc_util/internal/capturers.hpp:508-516, src/cwipc_capturer.cpp:152-160). */
+typedef int _cwipc_functype_count_devices(void);
+typedef cwipc_activesource *_cwipc_func_capturer_factory(const char *configFilename, char **errorMessage, uint64_t apiVersion);
+_CWIPC_UTIL_EXPORT int _cwipc_register_capturer(const char *name, _cwipc_functype_count_devices *countFunc, _cwipc_func_capturer_factory *factoryFunc);
 _CWIPC_UTIL_EXPORT cwipc_sink *cwipc_window(const char *title, char **errorMessage, uint64_t apiVersion);                    /* GUI: out of scope */
 _CWIPC_UTIL_EXPORT cwipc_activesource *cwipc_proxy(const char *host, int port, char **errorMessage, uint64_t apiVersion);    /* TCP transport: out of scope */
 

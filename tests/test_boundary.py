@@ -264,3 +264,34 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_capturer_registry(cwipc):
+    """Camera plugins register a factory (reference src/cwipc_capturer.cpp:152-160); cwipc_capturer dispatches on
+    the "type" of the configuration.  A plugin stand-in that hands out the synthetic source."""
+    import ctypes
+    dll = cwipc.cwipc_util_dll_load()
+    COUNT = ctypes.CFUNCTYPE(ctypes.c_int)
+    FACTORY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint64)
+    seen = []
+
+    def factory(config, errp, version):
+        seen.append(config)
+        err = ctypes.c_char_p()
+        return ctypes.cast(dll.cwipc_synthetic(0, 1000, ctypes.byref(err), version), ctypes.c_void_p).value
+
+    count_cb, factory_cb = COUNT(lambda: 0), FACTORY(factory)
+    dll._cwipc_register_capturer.argtypes = [ctypes.c_char_p, COUNT, FACTORY]
+    dll._cwipc_register_capturer.restype = ctypes.c_int
+    test_capturer_registry.keep = (count_cb, factory_cb)   # the library keeps the pointers
+    assert dll._cwipc_register_capturer(b"testcam", count_cb, factory_cb) == 1
+    src = cwipc.cwipc_capturer('{"version": 3, "system": {"type": "nested"}, "type": "testcam"}')
+    assert seen and seen[0].startswith(b'{"version"')
+    src.start()
+    pc = src.get()
+    assert pc.count() == 961
+    src.stop()
+    with pytest.raises(cwipc.CwipcError, match="not supported"):
+        cwipc.cwipc_capturer('{"type": "othercam"}')
+    with pytest.raises(cwipc.CwipcError, match="no supported cameras"):
+        cwipc.cwipc_capturer("auto")
