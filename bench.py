@@ -119,13 +119,20 @@ def main() -> None:
 
     if cwipc.cwipc_hip_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the filter path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    cwipc.cwipc_hip_set_device(local_rank)
+    # one rank per GPU; CWIPC_BENCH_BACKEND=gloo lets several ranks share a GPU (rehearsal of the N > 1 path on a
+    # one-GPU box: RCCL refuses two ranks on one device)
+    backend = os.environ.get("CWIPC_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    cwipc.cwipc_hip_set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     # ---- input: 4 device-resident copies of this rank's tile ----
     base = make_input(cwipc, args.npoints, angle=0.25 * rank)
@@ -156,9 +163,9 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    n_out = 0
     for i in range(args.warmup):
-        n_out = step(i).count()
+        step(i)
+    n_out = cwipc.cwipc_downsample(clouds[0], CELLSIZE).count()   # output points of this rank's own tile
 
     # ---- timed region ----
     fence()
@@ -168,7 +175,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     fused_points = out.count()

@@ -92,6 +92,11 @@ def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
             util.cwipc_hip_copy_device_aos(pc, local.data_ptr(), n * 16)
         ts, cs, has = pc.timestamp(), pc.cellsize(), True
     torch.cuda.current_stream().synchronize()
-    fused, ts, cs, _counts = all_gatherv_points(local, ts, cs, has, group)
+    if dist.get_backend(group) == "nccl":
+        fused, ts, cs, _counts = all_gatherv_points(local, ts, cs, has, group)
+    else:
+        # a process group without device collectives (gloo: rehearsals on one GPU): the exchange runs on host copies
+        fused, ts, cs, _counts = all_gatherv_points(local.cpu(), ts, cs, has, group)
+        fused = fused.to(dev)
     torch.cuda.current_stream().synchronize()
     return util.cwipc_hip_from_device_aos(fused.data_ptr() if fused.shape[0] else 0, fused.shape[0], ts, cs)
