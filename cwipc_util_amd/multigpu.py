@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["tiles_of_rank", "all_gatherv_points", "join_across_ranks"]
+__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks"]
 
 
 def tiles_of_rank(ntiles: int, rank: int, world: int) -> List[int]:
@@ -77,26 +77,131 @@ def all_gatherv_points(points: torch.Tensor, timestamp: int, cellsize: float, ha
     return fused, ts, cs, counts
 
 
+class SlotExchange:
+    """The same exchange for a stream of frames: one collective per frame instead of two.
+
+    Every rank owns a slot of `cap + 2` rows in a persistent buffer: two header rows
+    [count, has_cloud, cellsize bits, 0] [timestamp lo, timestamp hi, 0, 0] and its points.  One
+    all_gather of whole slots carries data and metadata together; the capacity is agreed once (a count
+    exchange on the first frame) and grown, by all ranks alike, when some rank's count outgrows it
+    (every rank sees every header, so all of them take the same decision and repeat the gather).
+    """
+
+    HEADER_ROWS = 2
+
+    def __init__(self, device: torch.device, group: Optional[dist.ProcessGroup] = None):
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.cap = 0
+        self.send: Optional[torch.Tensor] = None
+        self.recv: Optional[torch.Tensor] = None
+        self.collectives = 0   # for tests: how many collectives the last call needed
+        self._overflow: Optional[torch.Tensor] = None
+
+    def _resize(self, need: int) -> None:
+        cap = ((int(need * 1.25) + 4095) // 4096) * 4096
+        self.cap = max(cap, 4096)
+        rows = self.cap + self.HEADER_ROWS
+        self.send = torch.zeros((rows, 4), dtype=torch.int32, device=self.device)
+        self.recv = torch.zeros((self.world, rows, 4), dtype=torch.int32, device=self.device)
+
+    def _agree_on_capacity(self, n_local: int) -> None:
+        mine = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+        counts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(counts, mine, group=self.group)
+        self.collectives += 1
+        self._resize(max(int(c.item()) for c in counts))
+
+    def slot_points(self, n_local: int) -> torch.Tensor:
+        """Where this rank's points go (int32[n_local, 4]): its slot, or a buffer of its own while the slots
+        are too small (no collective here: ranks must never communicate on their own).  Fill it, then call gather()."""
+        if n_local <= self.cap:
+            self._overflow = None
+            return self.send[self.HEADER_ROWS:self.HEADER_ROWS + n_local]
+        self._overflow = torch.empty((n_local, 4), dtype=torch.int32, device=self.device)
+        return self._overflow
+
+    def gather(self, n_local: int, timestamp: int, cellsize: float, has_cloud: bool = True) -> Tuple[torch.Tensor, int, float, List[int]]:
+        """After the points are in slot_points(n_local): returns (fused int32[n_total, 4], min timestamp, min cellsize, counts).
+        Collective: every rank of the group calls it, once per frame."""
+        import struct
+        self.collectives = 0
+        if self.cap == 0:
+            self._agree_on_capacity(n_local)   # first frame, all ranks alike
+            self._adopt_overflow(n_local)
+        ts = int(timestamp) & 0xffffffffffffffff
+        as_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+        cs_bits = struct.unpack("<i", struct.pack("<f", float(cellsize)))[0]
+        header = torch.tensor([[n_local, 1 if has_cloud else 0, cs_bits, 0], [as_i32(ts & 0xffffffff), as_i32(ts >> 32), 0, 0]], dtype=torch.int32)
+        while True:
+            self.send[:self.HEADER_ROWS].copy_(header)
+            rows = self.cap + self.HEADER_ROWS
+            if self.device.type == "cuda":
+                dist.all_gather_into_tensor(self.recv.view(self.world * rows, 4), self.send, group=self.group)
+            else:   # gloo: list form, same bytes
+                dist.all_gather([self.recv[r] for r in range(self.world)], self.send, group=self.group)
+            self.collectives += 1
+            heads = self.recv[:, :self.HEADER_ROWS, :].cpu()
+            counts = [int(v) for v in heads[:, 0, 0].tolist()]
+            if max(counts) <= self.cap:
+                break
+            # somebody's cloud outgrew the slots (its points were not sent): every rank sees that in the
+            # headers, all grow alike and send again
+            keep = None if self._overflow is not None else self.send[self.HEADER_ROWS:self.HEADER_ROWS + n_local].clone()
+            self._resize(max(counts))
+            if keep is not None:
+                self.send[self.HEADER_ROWS:self.HEADER_ROWS + n_local] = keep
+            self._adopt_overflow(n_local)
+        part = heads[:, 0, 1] > 0
+        if bool(part.any()):
+            lo = heads[:, 1, 0].to(torch.int64) & 0xffffffff
+            hi = heads[:, 1, 1].to(torch.int64) & 0xffffffff
+            stamps = (hi << 32) | lo   # below 2^63 for any real timestamp
+            ts_min = int(stamps[part].min().item())
+            cs_min = float(heads[:, 0, 2][part].contiguous().view(torch.float32).min().item())
+        else:
+            ts_min, cs_min = 0, 0.0
+        if sum(counts) == 0:
+            return torch.empty((0, 4), dtype=torch.int32, device=self.device), ts_min, cs_min, counts
+        fused = torch.cat([self.recv[r, self.HEADER_ROWS:self.HEADER_ROWS + counts[r]] for r in range(self.world) if counts[r]], dim=0)
+        return fused, ts_min, cs_min, counts
+
+    def _adopt_overflow(self, n_local: int) -> None:
+        if self._overflow is not None and n_local <= self.cap:
+            self.send[self.HEADER_ROWS:self.HEADER_ROWS + n_local] = self._overflow
+            self._overflow = None
+
+
+_exchanges = {}
+
+
 def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
     """All ranks call this with their (device-resident) cloud, or None for "no tile this frame";
-    every rank gets the fused cloud as a new cwipc_pointcloud_wrapper.  GPU only."""
+    every rank gets the fused cloud as a new cwipc_pointcloud_wrapper.  GPU only.  Frame after frame this
+    is one collective (SlotExchange); the library's SoA -> AoS kernel writes straight into the send slot."""
     from . import util
     dev = torch.device("cuda", torch.cuda.current_device())
+    staged = dist.get_backend(group) != "nccl"   # no device collectives (gloo: rehearsals on one GPU): slots live on the host
+    key = (id(group), dev.index, staged)
+    ex = _exchanges.get(key)
+    if ex is None:
+        ex = _exchanges[key] = SlotExchange(torch.device("cpu") if staged else dev, group)
     if pc is None:
-        local = torch.empty((0, 4), dtype=torch.int32, device=dev)
-        ts, cs, has = 0, 0.0, False
+        n, ts, cs, has = 0, 0, 0.0, False
     else:
-        n = pc.count()
-        local = torch.empty((n, 4), dtype=torch.int32, device=dev)
-        if n:
-            util.cwipc_hip_copy_device_aos(pc, local.data_ptr(), n * 16)
-        ts, cs, has = pc.timestamp(), pc.cellsize(), True
-    torch.cuda.current_stream().synchronize()
-    if dist.get_backend(group) == "nccl":
-        fused, ts, cs, _counts = all_gatherv_points(local, ts, cs, has, group)
-    else:
-        # a process group without device collectives (gloo: rehearsals on one GPU): the exchange runs on host copies
-        fused, ts, cs, _counts = all_gatherv_points(local.cpu(), ts, cs, has, group)
+        n, ts, cs, has = pc.count(), pc.timestamp(), pc.cellsize(), True
+    slot = ex.slot_points(n)
+    if n:
+        if staged:
+            tmp = torch.empty((n, 4), dtype=torch.int32, device=dev)
+            util.cwipc_hip_copy_device_aos(pc, tmp.data_ptr(), n * 16)
+            slot.copy_(tmp)
+        else:
+            torch.cuda.current_stream().synchronize()          # the slot tensor is ready for another stream's kernel
+            util.cwipc_hip_copy_device_aos(pc, slot.data_ptr(), n * 16)   # returns after the library's stream has finished
+    fused, ts, cs, _counts = ex.gather(n, ts, cs, has)
+    if staged:
         fused = fused.to(dev)
     torch.cuda.current_stream().synchronize()
     return util.cwipc_hip_from_device_aos(fused.data_ptr() if fused.shape[0] else 0, fused.shape[0], ts, cs)

@@ -95,3 +95,59 @@ def test_all_gatherv_join_gloo(tmp_path, world, case):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _stream_worker(rank: int, world: int, port: int, result_dir: str):
+    """A stream of frames through SlotExchange: one collective per frame once the slots are sized, regrowth when a
+    tile outgrows them, empty and missing tiles in between."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from cwipc_util_amd.multigpu import SlotExchange
+        from oracle import oracle
+        ex = SlotExchange(torch.device("cpu"))
+        # (points of rank r in frame f, has_cloud)
+        def frame_tile(f, r):
+            n = [3000, 3500, 0, 3200, 20000, 100, 0, 21000][f] + 137 * r
+            if f == 2:
+                return oracle.empty(0), r != 0          # an empty frame; rank 0 has no cloud at all
+            if f == 6 and r == 1:
+                return oracle.empty(0), False
+            pts, _ = oracle.synthetic(2 * n + 1000, 0.1 * f + r)
+            return pts[:n].copy(), True
+        collectives = []
+        for f in range(8):
+            pts, has = frame_tile(f, rank)
+            slot = ex.slot_points(len(pts))
+            if len(pts):
+                slot.copy_(torch.from_numpy(np.ascontiguousarray(pts).view(np.int32).reshape(-1, 4).copy()))
+            fused, ts, cs, counts = ex.gather(len(pts), 1000 + 10 * f - rank, 0.01 * (rank + 1), has)
+            collectives.append(ex.collectives)
+            exp, ets, ecs = None, None, None
+            for r in range(world):
+                p, h = frame_tile(f, r)
+                if not h:
+                    continue
+                exp = p if exp is None else oracle.join(exp, p)
+                ets = 1000 + 10 * f - r if ets is None else min(ets, 1000 + 10 * f - r)
+                ecs = np.float32(0.01 * (r + 1)) if ecs is None else min(ecs, np.float32(0.01 * (r + 1)))
+            if exp is None:
+                exp, ets, ecs = oracle.empty(0), 0, 0.0
+            got = fused.numpy().reshape(-1).view(exp.dtype) if fused.shape[0] else exp[:0]
+            assert counts == [len(frame_tile(f, r)[0]) for r in range(world)], (f, counts)
+            assert got.tobytes() == exp.tobytes(), f"frame {f}: fused cloud differs from the cwipc_join fold"
+            assert ts == ets and cs == pytest.approx(float(ecs), rel=0, abs=0), (f, ts, ets, cs, ecs)
+        # frame 0: count exchange + gather; frame 4 and 7 outgrow the slots: one extra gather; all others: one collective
+        assert collectives[0] == 2 and collectives[1] == 1 and collectives[2] == 1 and collectives[3] == 1, collectives
+        assert collectives[4] == 2 and collectives[5] == 1 and collectives[6] == 1, collectives
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slot_exchange_stream_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_stream_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
