@@ -588,6 +588,38 @@ def test_remove_outliers_tiny_clouds(gpu, oracle):
         assert same(got, oracle.remove_outliers(pts, 16, 1.0, False)), n
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_remove_outliers_random_configurations(gpu, oracle, seed):
+    """Differential test of the k-NN statistics (d_i bit for bit) over random shapes, densities and k:
+    exercises the register list (k <= 16, k <= 32), the LDS list (k > 32), searches that need many rings,
+    coincident points, grids that degenerate to a line or a plane."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([40, 200, 1000, 5000, 30000]))
+    k = int(rng.choice([1, 4, 16, 17, 30, 32, 33, 50]))
+    if n <= k:
+        n = k + 7
+    kind = rng.choice(["box", "clusters", "line", "sheet", "dupes"])
+    scale = float(rng.choice([0.1, 1.0, 25.0]))
+    if kind == "box":
+        xyz = rng.random((n, 3)) * scale
+    elif kind == "clusters":
+        centres = rng.random((5, 3)) * scale
+        xyz = centres[rng.integers(0, 5, n)] + rng.normal(0, scale * 0.003, (n, 3))
+    elif kind == "line":
+        t = rng.random(n)
+        xyz = np.stack([t * scale, np.zeros(n), np.zeros(n)], axis=1)
+    elif kind == "sheet":
+        xyz = np.stack([rng.random(n) * scale, rng.random(n) * scale, np.full(n, 0.25)], axis=1)
+    else:   # many coincident points
+        base = rng.random((max(n // 10, 1), 3)) * scale
+        xyz = base[rng.integers(0, len(base), n)]
+    xyz += rng.choice([0.0, -3.0, 100.0])
+    pts = oracle.empty(n)
+    pts['x'], pts['y'], pts['z'] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts['tile'] = 1 << rng.integers(0, 3, n)
+    check_sor(gpu, oracle, pts, 0.0, k, float(rng.choice([0.5, 1.0, 2.0])))
+
+
 # ---------------------------------------------------------------------------
 # chains and residency
 # ---------------------------------------------------------------------------
