@@ -1711,6 +1711,27 @@ __global__ void first_point_kernel(const float *__restrict__ x, const float *__r
     host_out[0] = x[0]; host_out[1] = y[0]; host_out[2] = z[0];
 }
 
+// The first FINITE point (the octree skips the others, so it is the anchor): one workgroup walks the
+// cloud from the front, 1024 points at a time, until a chunk holds one.  out = x, y, z, found.
+__global__ void __launch_bounds__(1024) first_finite_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
+                                                           float *__restrict__ host_out) {
+    __shared__ unsigned long long s_first;
+    for (size_t base = 0; base < n; base += 1024) {
+        if (threadIdx.x == 0) s_first = ~0ull;
+        __syncthreads();
+        const size_t i = base + threadIdx.x;
+        if (i < n && isfinite(x[i]) && isfinite(y[i]) && isfinite(z[i])) atomicMin(&s_first, (unsigned long long)i);
+        __syncthreads();
+        const unsigned long long f = s_first;
+        __syncthreads();
+        if (f != ~0ull) {
+            if (threadIdx.x == 0) { host_out[0] = x[f]; host_out[1] = y[f]; host_out[2] = z[f]; host_out[3] = 1.0f; }
+            return;
+        }
+    }
+    if (threadIdx.x == 0) host_out[3] = 0.0f;
+}
+
 bool fetch_first_point(const DeviceSoA &src, ThreadCtx &c) {
     if (src.has_first) return true;
     float *h = (float *)c.host_words;
@@ -1777,11 +1798,18 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     memset(faces_host, 0, sizeof(faces_host));
     if (leaf_split) {
         if (!fetch_first_point(src, c)) return nullptr;
-        if (!(std::isfinite(src.first[0]) && std::isfinite(src.first[1]) && std::isfinite(src.first[2]))) {
-            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the first point of the cloud is not finite");
-            return nullptr;
+        float anchor[3] = {src.first[0], src.first[1], src.first[2]};
+        if (!(std::isfinite(anchor[0]) && std::isfinite(anchor[1]) && std::isfinite(anchor[2]))) {
+            // the octree skips non-finite points (addPointsFromInputCloud): its first point is the first finite one
+            float *h = (float *)c.host_words;
+            hipLaunchKernelGGL(first_finite_kernel, dim3(1), dim3(1024), 0, c.stream, src.x(), src.y(), src.z(), n, h);
+            bool ok = hipGetLastError() == hipSuccess;
+            ok = c.sync() && ok;
+            if (!ok) { hip_failed(hipGetLastError(), "search for the first finite point", __FILE__, __LINE__); return nullptr; }
+            if (h[3] == 0.0f) return soa_alloc(0);   // no finite point at all: no leaves, an empty cloud
+            anchor[0] = h[0]; anchor[1] = h[1]; anchor[2] = h[2];
         }
-        const double pp[3] = {(double)src.first[0], (double)src.first[1], (double)src.first[2]};
+        const double pp[3] = {(double)anchor[0], (double)anchor[1], (double)anchor[2]};
         first_box(pp, P.res, P.mn0, P.mx0, P.depth0);
         for (int a = 0; a < 3; a++) {
             P.ib[a] = (int)floor(P.mn0[a] / P.leaf_d);

@@ -477,6 +477,26 @@ def test_downsample_random_configurations(gpu, oracle, seed):
         check_downsample(gpu, oracle, pts, 0.0, -cell)
 
 
+def test_downsample_non_finite_points(gpu, oracle, synth):
+    """The octree skips non-finite points, so its lattice is anchored at the first FINITE point; a cloud
+    without any gives an empty result (no leaves), not an error."""
+    pts, cs = synth(20000)
+    p = pts.copy()
+    p['x'][0] = np.nan
+    p['y'][1] = np.inf
+    p['z'][2] = -np.inf
+    p['x'][5000:5010] = np.nan
+    got, exp = check_downsample(gpu, oracle, p, cs, 0.02)
+    ref, _ = oracle.downsample(pts[3:][np.isfinite(p['x'][3:])], cs, 0.02)
+    assert same(exp, ref)
+    late = pts.copy()
+    late['x'][:3000] = np.nan            # the first finite point lies beyond the first chunks
+    check_downsample(gpu, oracle, late, cs, 0.02)
+    none = pts[:100].copy()
+    none['y'] = np.nan
+    assert gpu.cwipc_downsample(make_cloud(gpu, none, cs), 0.02).count() == 0 == len(oracle.downsample(none, cs, 0.02)[0])
+
+
 def test_downsample_single_point_and_duplicates(gpu, oracle):
     pts = oracle.empty(1)
     pts['x'], pts['y'], pts['z'], pts['r'], pts['tile'] = 0.5, -0.25, 3.0, 200, 4
