@@ -11,7 +11,9 @@ Workload (BASELINE.json configs[1]): cwipc_synthetic(npoints=10 000 000) -> N = 
 
 N > 1 (weak scaling): every rank holds one camera tile of the same size (tile mask 1 << rank),
 runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join
-(cwipc_util_amd.multigpu) -- the path's one exchange step.
+(cwipc_util_amd.multigpu) -- the path's one exchange step.  Frames stream: the join of frame i runs on a
+worker thread while the main thread downsamples frame i + 1 (at most two frames in flight; all joins are
+complete when the timed region ends).
 
 One JSON line on rank 0.  `value` = points filtered by all ranks / wall time of the K timed steps
 (max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel
@@ -149,14 +151,59 @@ def main() -> None:
         clouds.append(pc)
     del base
 
+    # N > 1: the join of frame i (a worker thread, as in the reference: net/source_synchronizer.py:17,184 joins on
+    # a worker thread too) overlaps the downsample of frame i + 1; at most two frames are in flight, and every
+    # frame's join has finished when the timed region ends.  CWIPC_BENCH_PIPELINE=0 runs them one after the other.
+    pipelined = world > 1 and os.environ.get("CWIPC_BENCH_PIPELINE", "1") != "0"
+    joiner = None
+    if world > 1:
+        from cwipc_util_amd.multigpu import join_across_ranks
+    if pipelined:
+        import queue
+        import threading
+
+        class Joiner:
+            def __init__(self):
+                self.todo = queue.Queue(maxsize=2)
+                self.last = None
+                self.error = None
+                self.thread = threading.Thread(target=self.run, daemon=True)
+                self.thread.start()
+
+            def run(self):
+                torch.cuda.set_device(device_index)
+                while True:
+                    item = self.todo.get()
+                    try:
+                        if item is None:
+                            return
+                        if self.error is None:
+                            self.last = join_across_ranks(item)
+                    except BaseException as e:   # keep draining: the main thread must not block on a full queue
+                        self.error = e
+                    finally:
+                        self.todo.task_done()
+
+            def drain(self):
+                self.todo.join()
+                if self.error is not None:
+                    raise self.error
+                return self.last
+
+        joiner = Joiner()
+
     def step(i: int):
         out = cwipc.cwipc_downsample(clouds[i % NCOPIES], CELLSIZE)
+        if joiner is not None:
+            joiner.todo.put(out)
+            return out
         if world > 1:
-            from cwipc_util_amd.multigpu import join_across_ranks
             out = join_across_ranks(out)
         return out
 
     def fence():
+        if joiner is not None:
+            joiner.drain()
         cwipc.util.cwipc_util_dll_load().cwipc_hip_synchronize()
         torch.cuda.synchronize()
         if dist is not None:
@@ -178,7 +225,7 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    fused_points = out.count()
+    fused_points = (joiner.drain() if joiner is not None else out).count()
 
     # ---- second pass over the same steps with per-kernel hipEvent timing ----
     with cwipc.cwipc_hip_profile() as prof:
@@ -209,7 +256,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"cwipc_synthetic({args.npoints}) -> cwipc_downsample(+{CELLSIZE}) [BASELINE configs[1]]"
-                            + (f" per rank, tile masks 1<<rank, + all-gatherv join over {world} ranks" if world > 1 else ""),
+                            + (f" per rank, tile masks 1<<rank, + all-gatherv join over {world} ranks"
+                               + (" (join of frame i overlaps the downsample of frame i+1)" if pipelined else "") if world > 1 else ""),
                 "points_per_gpu": n,
                 "bytes_per_gpu": 16 * n,
                 "outputs_per_gpu": n_out,
@@ -238,6 +286,9 @@ def main() -> None:
             result["cpu_baseline"] = cpu_baseline(pts, pc_cellsize)
         print(json.dumps(result))
 
+    if joiner is not None:
+        joiner.todo.put(None)
+        joiner.thread.join()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
