@@ -773,3 +773,32 @@ def test_filters_from_several_threads(gpu, oracle, synth):
     for pc in produced:
         got = pc.get_numpy_array()
         assert len(got) == len(exp) and (got['tile'] == exp['tile']).all()
+
+
+def test_no_leaks_over_many_calls(gpu, synth):
+    """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
+    import gc
+    pts, cs = synth(100000)
+    dll = gpu.cwipc_util_dll_load()
+
+    def frame():
+        pc = make_cloud(gpu, pts, cs)
+        a = gpu.cwipc_downsample(pc, 0.01)
+        b = gpu.cwipc_remove_outliers(a, 16, 1.0, False)
+        c = gpu.cwipc_tilefilter(b, 1)
+        d = gpu.cwipc_join(c, gpu.cwipc_downsample(pc, -0.02))
+        return d.get_numpy_array().shape[0]
+
+    for _ in range(20):
+        frame()
+    gc.collect()
+    dll.cwipc_hip_synchronize()
+    bytes0 = gpu.cwipc_hip_pool_bytes() if hasattr(gpu, 'cwipc_hip_pool_bytes') else dll.cwipc_hip_pool_bytes()
+    dangling0 = gpu.cwipc_dangling_allocations(False)
+    counts = {frame() for _ in range(200)}
+    gc.collect()
+    dll.cwipc_hip_synchronize()
+    bytes1 = gpu.cwipc_hip_pool_bytes() if hasattr(gpu, 'cwipc_hip_pool_bytes') else dll.cwipc_hip_pool_bytes()
+    assert len(counts) == 1                       # same input, same result, every time
+    assert bytes1 == bytes0, (bytes0, bytes1)     # the pool recycles; nothing new was needed
+    assert gpu.cwipc_dangling_allocations(False) == dangling0
