@@ -247,27 +247,6 @@ __device__ __forceinline__ void mark_occupied(const VoxWork &W, uint32_t key) {
     atomicOr(&W.bitmaps[(size_t)(key >> CELL_BITS) * BITWORDS + (cell >> 5)], 1u << (cell & 31u));
 }
 
-// Slow path (workgroup table saturated by incoherent input): one lane updates a whole record.
-__device__ __forceinline__ void global_insert_lane(const VoxWork &W, uint32_t list_cap, uint32_t key, long long sx, long long sy, long long sz,
-                                                   unsigned long long cr, unsigned long long gb, uint32_t tile) {
-    unsigned long long *rec = record_ptr(W, key);
-    atomicAdd(&rec[0], (unsigned long long)sx);
-    atomicAdd(&rec[1], (unsigned long long)sy);
-    atomicAdd(&rec[2], (unsigned long long)sz);
-    const unsigned long long old = atomicAdd(&rec[3], cr);
-    atomicAdd(&rec[4], gb);
-    atomicOr(&rec[7], (unsigned long long)tile);
-    if ((old >> 32) == 0) {
-        mark_occupied(W, key);
-        atomicAdd(&W.seg_count[slice_of(key)], 1u);
-        const uint32_t idx = atomicAdd(&W.ctrl[C_COUNT], 1u);
-        if (list_cap) {   // 0: the caller does not keep the list
-            if (idx < list_cap) W.occupied[idx] = key;
-            else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------
@@ -378,18 +357,76 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
     if (__ballot(need_or) != 0ull) {
         if (need_or) atomicOr(&L.tile[slot], r.tile);
     }
-    if (__builtin_expect(active && pending, 0)) {   // table saturated (sparse or incoherent input): straight to the global records
-        atomicAdd(&L.nfallback, 1u);
-        const uint32_t cnt = r.cr >> 16;
-        const long long bias = (long long)cnt * P.q_bias;
-        uint32_t gkey = r.key;
-        if (P.local_leaves) {
-            const uint32_t gid = leaf_lookup(W, P.leaf_mask, L.leaf_tab[r.key >> CELL_BITS]);
-            gkey = (gid << CELL_BITS) | (r.key & ((1u << CELL_BITS) - 1));
-            if (gid == 0xffffffffu) return;   // ERR_LEAVES is set: the pass is discarded
+    // ---- table saturated (sparse or incoherent input): the runs go straight to the global records ----
+    const unsigned long long failed = __ballot(active && pending);
+    if (__builtin_expect(failed != 0ull, 0)) {
+        const bool mine = active && pending;
+        const int lane = threadIdx.x & 63;
+        // the record of this lane's run (global leaf id * CELLS + cell), ~0 if it has none
+        uint32_t rec = 0xffffffffu;
+        if (mine) {
+            atomicAdd(&L.nfallback, 1u);
+            uint32_t gid = r.key >> CELL_BITS;
+            if (P.local_leaves) {
+                gid = L.leaf_gid[r.key >> CELL_BITS];
+                if (gid >= 0xfffffffeu) gid = leaf_lookup(W, P.leaf_mask, L.leaf_tab[r.key >> CELL_BITS]);   // ~0: ERR_LEAVES is set, the pass is discarded
+            }
+            if (gid != 0xffffffffu) rec = gid * (uint32_t)CELLS + (r.key & ((1u << CELL_BITS) - 1));
         }
-        global_insert_lane(W, P.want_list ? P.list_cap : 0u, gkey, (long long)r.qx - bias, (long long)r.qy - bias, (long long)r.qz - bias, u64_of(r.cr & 0xffffu, cnt),
-                           u64_of(r.gb & 0xffffu, r.gb >> 16), r.tile);
+        // Eight lanes per run update its 64-byte record with one instruction (one cache-line operation
+        // in L2 instead of six: incoherent clouds are bound by exactly that), eight runs per instruction.
+#pragma unroll 1
+        for (int b = 0; b < 8; b++) {
+            if (((failed >> (8 * b)) & 0xffull) == 0ull) continue;
+            const int src = 8 * b + (lane >> 3), sub = lane & 7;
+            const uint32_t s_rec = (uint32_t)__shfl((int)rec, src, 64);
+            const uint32_t s_qx = (uint32_t)__shfl((int)r.qx, src, 64), s_qy = (uint32_t)__shfl((int)r.qy, src, 64), s_qz = (uint32_t)__shfl((int)r.qz, src, 64);
+            const uint32_t s_cr = (uint32_t)__shfl((int)r.cr, src, 64), s_gb = (uint32_t)__shfl((int)r.gb, src, 64), s_tile = (uint32_t)__shfl((int)r.tile, src, 64);
+            bool first = false;
+            uint32_t s_key = 0;
+            if (s_rec != 0xffffffffu && sub < 7) {
+                const uint32_t cnt = s_cr >> 16;
+                const long long bias = (long long)cnt * P.q_bias;
+                unsigned long long val;
+                switch (sub) {
+                case 0: val = (unsigned long long)((long long)s_qx - bias); break;
+                case 1: val = (unsigned long long)((long long)s_qy - bias); break;
+                case 2: val = (unsigned long long)((long long)s_qz - bias); break;
+                case 3: val = u64_of(s_cr & 0xffffu, cnt); break;                 // count << 32 | sum r
+                case 4: val = u64_of(s_gb & 0xffffu, s_gb >> 16); break;         // sum g << 32 | sum b
+                case 5:   // tile bits 0-3 as 16-bit contribution counters
+                    val = (unsigned long long)(s_tile & 1u) | ((unsigned long long)((s_tile >> 1) & 1u) << 16) |
+                          ((unsigned long long)((s_tile >> 2) & 1u) << 32) | ((unsigned long long)((s_tile >> 3) & 1u) << 48);
+                    break;
+                default:  // tile bits 4-7
+                    val = (unsigned long long)((s_tile >> 4) & 1u) | ((unsigned long long)((s_tile >> 5) & 1u) << 16) |
+                          ((unsigned long long)((s_tile >> 6) & 1u) << 32) | ((unsigned long long)((s_tile >> 7) & 1u) << 48);
+                    break;
+                }
+                const unsigned long long old = atomicAdd(&W.records[(size_t)s_rec * RECORD_WORDS + sub], val);
+                if (sub == 3 && (old >> 32) == 0) {
+                    first = true;
+                    s_key = ((s_rec / (uint32_t)CELLS) << CELL_BITS) | (s_rec % (uint32_t)CELLS);
+                    mark_occupied(W, s_key);
+                    atomicAdd(&W.seg_count[slice_of(s_key)], 1u);
+                }
+            }
+            // records touched for the first time: counted (and listed) with one atomic per instruction
+            const unsigned long long news = __ballot(first);
+            if (news != 0ull) {
+                const uint32_t nnew = (uint32_t)__popcll(news);
+                uint32_t base = 0;
+                if (lane == __ffsll((long long)news) - 1) base = atomicAdd(&W.ctrl[C_COUNT], nnew);
+                if (P.want_list) {
+                    base = (uint32_t)__shfl((int)base, __ffsll((long long)news) - 1, 64);
+                    if (first) {
+                        const uint32_t idx = base + (uint32_t)__popcll(news & ((1ull << lane) - 1ull));
+                        if (idx < P.list_cap) W.occupied[idx] = s_key;
+                        else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+                    }
+                }
+            }
+        }
     }
 }
 
