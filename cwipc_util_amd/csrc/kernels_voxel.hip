@@ -1652,6 +1652,7 @@ struct Workspace {
     uint32_t seq = 0;                  // sequence number of the last pass (never 0 once used)
     int shrink = 0;                    // log2 of how much smaller than "one workgroup per CU" the workgroups are made (sparse clouds)
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
+    bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
     size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
     float hint_cell = 0.f;
     bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
@@ -1803,6 +1804,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     if (ws.hint_cell != cellsize || n > 2 * ws.hint_n || 2 * n < ws.hint_n) {   // another kind of cloud: start over
         ws.shrink = 0;
         ws.calm = 0;
+        ws.incoherent = false;
     }
     ws.hint_cell = cellsize;
     ws.hint_n = n;
@@ -1940,7 +1942,13 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         {
             // adapt the workgroup size for the next call
             const uint32_t fallbacks = c.host_words[C_FALLBACK], maxload = c.host_words[C_MAXLOAD];
-            if ((size_t)fallbacks * 64 > n && ws.shrink < 6) {
+            if (ws.incoherent) {
+                // nothing to adapt: this kind of cloud defeats the table whatever its size
+            } else if (ws.shrink >= 2 && (size_t)fallbacks * 2 > n) {
+                ws.incoherent = true;   // smaller workgroups did not help: points in no order at all
+                ws.shrink = 0;
+                ws.calm = 0;
+            } else if ((size_t)fallbacks * 64 > n && ws.shrink < 6) {
                 ws.shrink++;
                 ws.calm = 0;
             } else if (ws.shrink > 0 && fallbacks == 0 && maxload * 3 < (uint32_t)LTAB) {
