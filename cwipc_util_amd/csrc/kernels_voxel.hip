@@ -1420,11 +1420,19 @@ __device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W
 // earlier slices, ranks of the slice's cells from a popcount scan, then gather, emit and clean.
 // Replaces the key sort: no pass over the outputs other than the emit itself.
 
-__global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, VoxWork W, uint32_t leaf_cap, uint32_t m, uint32_t *order,
-                                                                 float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
-                                                                 uint32_t *__restrict__ ow) {
+// speculative != 0: launched before the host knows the outcome of the pass, into a result buffer sized from
+// the previous call: the kernel takes the count from the control block and does nothing at all when the pass
+// reported an error or the count exceeds `m_or_cap` (the host then runs it again, with the facts).
+__global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, VoxWork W, uint32_t leaf_cap, uint32_t m_or_cap, int speculative,
+                                                                 uint32_t *order, float *__restrict__ ox, float *__restrict__ oy,
+                                                                 float *__restrict__ oz, uint32_t *__restrict__ ow) {
     __shared__ uint32_t wave_tot[RANK_THREADS / 64];
     __shared__ uint32_t s_base;
+    uint32_t m = m_or_cap;
+    if (speculative) {
+        m = W.ctrl[C_COUNT];
+        if (W.ctrl[C_ERR] != 0u || m > m_or_cap || m == 0u) return;
+    }
     const uint32_t p = blockIdx.x / RANK_SEGS, seg = blockIdx.x % RANK_SEGS;
     const unsigned long long lp = W.leaf_keys[p];
     if (lp == 0ull) return;
@@ -1650,6 +1658,7 @@ struct Workspace {
     size_t head_bytes = 0;             // bytes of one block
     int parity = 0;                    // block of the next pass
     uint32_t seq = 0;                  // sequence number of the last pass (never 0 once used)
+    uint32_t last_m = 0;               // outputs of this thread's last octree pass (sizes the speculative result of the next)
     int shrink = 0;                    // log2 of how much smaller than "one workgroup per CU" the workgroups are made (sparse clouds)
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
     bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
@@ -1920,6 +1929,19 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         ok = hipGetLastError() == hipSuccess;
         ws.head_clean[1 - blk] = ok;
         ws.parity = 1 - blk;
+        // Octree variant: the finalize pass goes out right behind the replay kernel, before the host knows the
+        // count, into a result sized from the previous call of this thread (+25 %); it checks count and error
+        // word on the device and leaves everything untouched if they do not fit.
+        std::shared_ptr<DeviceSoA> spec_dst;
+        uint32_t spec_cap = 0;
+        if (ok && leaf_split && ws.last_m > 0 && !profiling_enabled()) {
+            spec_cap = ws.last_m + ws.last_m / 4 + 1024;
+            spec_dst = soa_alloc(spec_cap);
+            if (spec_dst) {
+                hipLaunchKernelGGL(rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, spec_cap, 1, ws.order,
+                                   spec_dst->x(), spec_dst->y(), spec_dst->z(), spec_dst->rgbt());
+            }
+        }
         // wait for the replay kernel's sequence number in pinned memory (a few hundred microseconds of
         // polling at most, then the ordinary stream wait, which also reports launch failures)
         if (ok && !profiling_enabled()) {
@@ -1965,7 +1987,16 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         const unsigned mgrid = (m + 255) / 256;
 
         bool ranked = false;
-        if (!err && m && leaf_split) {
+        if (leaf_split) ws.last_m = err ? 0 : m;
+        if (!err && m && leaf_split && spec_dst && m <= spec_cap) {
+            // the speculative finalize pass is doing the work: the result uses the first m slots of its planes
+            dst = spec_dst;
+            dst->npoints = m;
+            dst->mark_pending(c.stream);
+            ranked = true;
+        }
+        spec_dst.reset();
+        if (!ranked && !err && m && leaf_split) {
             // octree path: rank the occupied cells through the bitmaps, emit, clean -- no sort.  The
             // replay kernel has already checked everything this pass could trip over, so the call
             // returns with it in flight: the result carries a `ready` event, later work of this thread
@@ -1974,7 +2005,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             if (!dst) {
                 err |= 0x80000000u;
             } else {
-                CW_LAUNCH("rank_emit", rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, m, ws.order,
+                CW_LAUNCH("rank_emit", rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, m, 0, ws.order,
                           dst->x(), dst->y(), dst->z(), dst->rgbt());
                 dst->mark_pending(c.stream);
                 ranked = true;
