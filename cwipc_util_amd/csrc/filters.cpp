@@ -51,34 +51,49 @@ cwipc_pointcloud *wrap(std::shared_ptr<DeviceSoA> planes, uint64_t timestamp, fl
 
 }  // namespace
 
-// Stable compaction driver: count -> scan -> (host learns the total, allocates
-// exactly) -> scatter.
+// Stable compaction driver: count -> scan -> scatter, back to back with one wait at the end.  The
+// output planes have room for every input point (the kept count is known only when the kernels are
+// done; the scan kernel writes it into the thread's pinned words); a result that uses less than a
+// sixteenth of that room is copied into a buffer of its own size.
 std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p) {
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     size_t n = src.npoints;
     if (n == 0) return soa_alloc(0);
     size_t nb = k::compact_blocks(n);
-    uint32_t *counts = (uint32_t *)pool_alloc((nb + 1) * sizeof(uint32_t));
-    if (!counts) return nullptr;
-    uint32_t *total_dev = counts + nb;
+    uint32_t *counts = (uint32_t *)pool_alloc(nb * sizeof(uint32_t));
+    auto dst = soa_alloc(n);
+    if (!counts || !dst) { pool_free(counts); return nullptr; }
+    c.host_words[0] = 0xffffffffu;
     k::compact_count(src, p, counts, c.stream);
-    k::compact_scan(counts, nb, total_dev, c.stream);
-    bool ok = hipMemcpyAsync(c.host_words, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
-    ok = c.sync() && ok;
-    std::shared_ptr<DeviceSoA> dst;
-    if (ok) {
-        size_t kept = c.host_words[0];
-        dst = soa_alloc(kept);
-        if (dst && kept) {
-            k::compact_scatter(src, p, counts, *dst, c.stream);
-            if (!c.sync()) dst.reset();
-        }
-    } else {
-        hip_failed(hipGetLastError(), "compaction", __FILE__, __LINE__);
-    }
+    k::compact_scan(counts, nb, c.host_words, c.stream);   // total -> pinned host word
+    k::compact_scatter(src, p, counts, *dst, c.stream);
+    const bool ok = c.sync();
     pool_free(counts);
-    return dst;
+    if (!ok) {
+        hip_failed(hipGetLastError(), "compaction", __FILE__, __LINE__);
+        return nullptr;
+    }
+    const size_t kept = c.host_words[0];
+    if (kept > n) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip", "compaction: inconsistent count");
+        return nullptr;
+    }
+    if (kept * 16 >= n) {
+        dst->npoints = kept;   // the planes keep their spacing (stride), only the count shrinks
+        return dst;
+    }
+    auto small = soa_alloc(kept);
+    if (!small) return nullptr;
+    if (kept) {
+        bool copied = hipMemcpyAsync(small->x(), dst->x(), kept * 4, hipMemcpyDeviceToDevice, c.stream) == hipSuccess &&
+                      hipMemcpyAsync(small->y(), dst->y(), kept * 4, hipMemcpyDeviceToDevice, c.stream) == hipSuccess &&
+                      hipMemcpyAsync(small->z(), dst->z(), kept * 4, hipMemcpyDeviceToDevice, c.stream) == hipSuccess &&
+                      hipMemcpyAsync(small->rgbt(), dst->rgbt(), kept * 4, hipMemcpyDeviceToDevice, c.stream) == hipSuccess;
+        copied = c.sync() && copied;
+        if (!copied) { hip_failed(hipGetLastError(), "compaction", __FILE__, __LINE__); return nullptr; }
+    }
+    return small;
 }
 
 }  // namespace cwipc_amd
