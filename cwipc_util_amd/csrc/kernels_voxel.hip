@@ -96,8 +96,7 @@ constexpr uint32_t Q_BIAS = 1u << 21, Q_BIAS_WIDE = 1u << 19;
 constexpr float G_CHECK = 4.0e6f, G_CHECK_WIDE = 33554432.0f;
 constexpr int RECORD_WORDS = 8;                // 64-byte records: sx sy sz cr gb tlo thi tor
 constexpr int FACES = 128;                     // leaf faces per axis with a precomputed threshold
-constexpr int FACE_BACK = 63;
-constexpr uint32_t REPLAY_LDS_RANGES = 4096;   // wave boxes the replay kernel keeps in LDS (96 KB)                  // the table starts 63 faces below the first point's leaf
+constexpr int FACE_BACK = 63;                  // the table starts 63 faces below the first point's leaf
 
 enum : uint32_t {
     ERR_RANGE = 1,           // voxel index outside +-2^26, or leaf index outside +-2^20
@@ -1137,12 +1136,8 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         s_depth = P.depth0;
         s_events = 0;
     }
-    // the wave boxes are searched once per growth step: keep them in LDS when they fit
-    extern __shared__ float s_boxes[];
-    const bool cached = nranges <= REPLAY_LDS_RANGES;
-    if (cached) {
-        for (uint32_t i = tid; i < nranges * 6; i += 1024) s_boxes[i] = bboxes[i];
-    }
+    // (the wave boxes are read from global memory: K1 has just written them, they sit in L2; staging them
+    // in 96 KB of LDS was measured to cost more than it saved)
     __syncthreads();
 
     const double eps = (double)FLT_EPSILON;
@@ -1170,7 +1165,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
             uint32_t mine = 0xffffffffu;
             for (uint32_t c = range + tid; c < nranges; c += 1024) {
                 float b[6];
-                for (int i = 0; i < 6; i++) b[i] = cached ? s_boxes[c * 6 + i] : bboxes[(size_t)c * 6 + i];
+                for (int i = 0; i < 6; i++) b[i] = bboxes[(size_t)c * 6 + i];
                 const bool viol = (double)b[0] < mn0 || (double)b[1] < mn1 || (double)b[2] < mn2 ||
                                   (double)b[3] >= mx0 || (double)b[4] >= mx1 || (double)b[5] >= mx2;
                 if (viol) { mine = c; break; }
@@ -1190,7 +1185,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         // has the same pattern, so the steps follow from the box of the range without reading its points.
         if (tid == 0) {
             float b[6];
-            for (int i = 0; i < 6; i++) b[i] = cached ? s_boxes[hit * 6 + i] : bboxes[(size_t)hit * 6 + i];
+            for (int i = 0; i < 6; i++) b[i] = bboxes[(size_t)hit * 6 + i];
             int resolved = 0;
             for (;;) {
                 bool up[3], any_low = false;
@@ -1713,8 +1708,6 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&octree_replay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(REPLAY_LDS_RANGES * 6 * sizeof(float))));
         ws.device = dev;
     }
     if (ws.leaf_cap < leaf_cap) {
@@ -1923,8 +1916,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(),
                       src.y(), src.z(), src.rgbt(), W);
         }
-        const size_t replay_lds = (leaf_split && nwaves <= REPLAY_LDS_RANGES) ? nwaves * 6 * sizeof(float) : 0;
-        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), replay_lds, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
+        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
                   ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), c.host_words, seq);
         ok = hipGetLastError() == hipSuccess;
         ws.head_clean[1 - blk] = ok;
