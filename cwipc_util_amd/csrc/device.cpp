@@ -211,18 +211,45 @@ ThreadCtx &tctx() {
     return ctx;
 }
 
+namespace {
+// Streams of threads that have ended.  They are handed to the next thread instead of being destroyed:
+// the `ready` event of a cloud that outlives its producing thread still refers to the stream it was
+// recorded on, and so does that event when it comes back through the event cache.
+struct RetiredStream { int device; hipStream_t stream; };
+std::mutex g_retired_mutex;
+std::vector<RetiredStream> *g_retired = new std::vector<RetiredStream>();   // never destroyed: threads may end after the statics
+
+hipStream_t retired_stream_take(int device) {
+    std::lock_guard<std::mutex> lock(g_retired_mutex);
+    for (size_t i = 0; i < g_retired->size(); i++) {
+        if ((*g_retired)[i].device == device) {
+            hipStream_t s = (*g_retired)[i].stream;
+            g_retired->erase(g_retired->begin() + (long)i);
+            return s;
+        }
+    }
+    return nullptr;
+}
+
+void retire_stream(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_retired_mutex);
+    g_retired->push_back(RetiredStream{device, s});
+}
+}  // namespace
+
 bool ThreadCtx::ensure() {
     int dev = current_device();
     CW_HIP_TRY(hipSetDevice(dev));
     if (stream && device == dev) return true;
     if (stream) {
         (void)hipStreamSynchronize(stream);
-        (void)hipStreamDestroy(stream);
+        retire_stream(device, stream);
         stream = nullptr;
         if (dev_words) { (void)hipFree(dev_words); dev_words = nullptr; }
     }
     device = dev;
-    CW_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream = retired_stream_take(dev);
+    if (!stream) CW_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (!host_words) CW_HIP_TRY(hipHostMalloc((void **)&host_words, 64 * sizeof(uint32_t), hipHostMallocDefault));
     CW_HIP_TRY(hipMalloc(&dev_words, 64 * sizeof(uint32_t)));
     return true;
@@ -251,7 +278,10 @@ bool ThreadCtx::sync() {
 
 ThreadCtx::~ThreadCtx() {
     // Runs at thread exit; the runtime may already be shutting down, so errors are ignored.
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) {
+        (void)hipStreamSynchronize(stream);
+        retire_stream(device, stream);
+    }
     if (pinned) (void)hipHostFree(pinned);
     if (host_words) (void)hipHostFree(host_words);
     if (dev_words) (void)hipFree(dev_words);
@@ -292,6 +322,7 @@ void DeviceSoA::mark_pending(hipStream_t producer) {
     ready = event_get();
     // without an event the only safe thing is to finish the work now
     if (!ready || hipEventRecord(ready, producer) != hipSuccess) {
+        (void)hipGetLastError();   // not left behind for the next launch check of this thread
         (void)hipStreamSynchronize(producer);
         if (ready) { event_put(ready); ready = nullptr; }
     }

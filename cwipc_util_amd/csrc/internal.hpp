@@ -125,7 +125,10 @@ struct DeviceSoA {
     hipEvent_t ready = nullptr;
     void mark_pending(hipStream_t producer);            // record `ready` on the producer's stream
     void wait_on(hipStream_t consumer) const {          // device-side wait, no host blocking
-        if (ready) (void)hipStreamWaitEvent(consumer, ready, 0);
+        if (ready && hipStreamWaitEvent(consumer, ready, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipEventSynchronize(ready);           // order on the host instead
+        }
     }
     void wait_host() const {                            // for consumers outside the library's streams
         if (ready) (void)hipEventSynchronize(ready);

@@ -1918,7 +1918,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         }
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
                   ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), c.host_words, seq);
-        ok = hipGetLastError() == hipSuccess;
+        const hipError_t launch_err = hipGetLastError();
+        ok = launch_err == hipSuccess;
         ws.head_clean[1 - blk] = ok;
         ws.parity = 1 - blk;
         // Octree variant: the finalize pass goes out right behind the replay kernel, before the host knows the
@@ -1950,7 +1951,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         } else {
             ok = c.sync() && ok;
         }
-        if (!ok) { hip_failed(hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
+        if (!ok) { hip_failed(launch_err != hipSuccess ? launch_err : hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
         uint32_t err = c.host_words[C_ERR];
         {

@@ -775,6 +775,38 @@ def test_filters_from_several_threads(gpu, oracle, synth):
         assert len(got) == len(exp) and (got['tile'] == exp['tile']).all()
 
 
+def test_results_outlive_the_thread_that_made_them(gpu, oracle, synth):
+    """Clouds made by threads that have ended (their streams retired, their `ready` events recycled) are
+    consumed, freed and followed by many more calls on the main thread; none of those may fail with an
+    error left over from an event of a stream that no longer exists."""
+    import threading, gc
+    pts, cs = synth(100000)
+    exp, _ = oracle.downsample(pts, cs, 0.01)
+    exp_t1 = oracle.tilefilter(exp, 1)
+    src = make_cloud(gpu, pts, cs, 3)
+    for generation in range(6):
+        made, errors = [], []
+
+        def worker():
+            try:
+                made.append(gpu.cwipc_tilefilter(gpu.cwipc_downsample(src, 0.01), 1))
+            except Exception as e:   # pragma: no cover
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker) for _ in range(3)]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        assert not errors
+        for pc in made:
+            assert gpu.cwipc_downsample(pc, 0.02).count() > 0    # device-side wait on the dead thread's event
+            assert pc.count() == len(exp_t1) > 0
+        del made
+        gc.collect()
+        for _ in range(10):                                      # recycled events, main thread's stream
+            out = gpu.cwipc_remove_outliers(gpu.cwipc_downsample(src, 0.01), 8, 1.0, False)
+            assert 0 < out.count() <= len(exp)
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
