@@ -461,9 +461,12 @@ struct FaceCache {
 struct PointOut {
     uint32_t key;   // cell inside the leaf grid, KEY_EMPTY if the point is skipped
     uint32_t nn;    // MODE 1: leaf relative to the cached faces, n0 | n1 << 2 | n2 << 4 with leaf_a = mc_a - 1 + n_a
-    int l0, l1, l2; // MODE 0 / 2: leaf lattice coordinates
+    // One set of registers for two things that are never alive together: leaf lattice coordinates (MODE 0 / 2,
+    // and MODE 1 once a step has gone the slow way), or the voxel index relative to cb (MODE 1, window test).
+    union { int l0; int u0; };
+    union { int l1; int u1; };
+    union { int l2; int u2; };
     uint32_t q0, q1, q2; // biased fixed-point offsets inside the voxel (>= 0)
-    int u0, u1, u2; // MODE 1: voxel index relative to cb (window test)
     bool seen;      // the point exists and is finite
 };
 
@@ -477,8 +480,8 @@ __device__ __forceinline__ void axis_cell(const K1Params &P, int ib, const FaceC
     if (MODE == 1) {
         // leaf = (face mc - 1) + [f >= T(mc)] + [f >= T(mc + 1)], valid while the voxel lies between faces mc - 1/2 and mc + 3/2
         u = ti - fc.cb;
-        n = (f >= fc.tlo ? 1 : 0) + (f >= fc.thi ? 1 : 0);
-        c = u - 64 * n;
+        n = (f >= fc.tlo ? -1 : 0) + (f >= fc.thi ? -1 : 0);   // minus the count: c is then one shift-and-add
+        c = (n << 6) + u;
     } else {
         const int t = ti - ib;
         if (MODE == 0) l = t >> 6;
@@ -494,12 +497,10 @@ __device__ __forceinline__ PointOut point_key(const K1Params &P, const FaceCache
                                               float fz, bool present) {
     PointOut o;
     int c0, c1, c2, n0 = 0, n1 = 0, n2 = 0;
-    o.l0 = o.l1 = o.l2 = 0;
-    o.u0 = o.u1 = o.u2 = 0;
     axis_cell<MODE>(P, P.ib0, f0, 0, fx, o.u0, n0, o.l0, c0, o.q0);
     axis_cell<MODE>(P, P.ib1, f1, 1, fy, o.u1, n1, o.l1, c1, o.q1);
     axis_cell<MODE>(P, P.ib2, f2, 2, fz, o.u2, n2, o.l2, c2, o.q2);
-    o.nn = (uint32_t)(n0 | (n1 << 2) | (n2 << 4));
+    o.nn = MODE == 1 ? (uint32_t)(-(n0 + (n1 << 2) + (n2 << 4))) : 0u;   // MODE 1: n_a = -(leaf position) here
     // Non-finite points are skipped as the octree does (addPointsFromInputCloud: isFinite).  One test for
     // the three coordinates: the sum is NaN or Inf iff one of them is (or they are beyond any sane range).
     o.seen = present && __builtin_isfinite(fx + fy + fz);
@@ -515,7 +516,6 @@ __device__ __forceinline__ PointOut point_key(const K1Params &P, const FaceCache
 __device__ __forceinline__ PointOut point_key_lookup(const K1Params &P, const float *faces, float fx, float fy, float fz, bool present, bool &off_table) {
     PointOut o;
     o.nn = 0;
-    o.u0 = o.u1 = o.u2 = 0;
     int c[3], l[3];
     uint32_t q[3];
     const float f[3] = {fx, fy, fz};
@@ -560,6 +560,18 @@ __device__ __forceinline__ PointAdd point_add(uint32_t w) {
 __device__ __forceinline__ void add_point(Run32 &r, const PointOut &o, const PointAdd &a) {
     r.qx += o.q0; r.qy += o.q1; r.qz += o.q2;
     r.cr += a.cr; r.gb += a.gb; r.tile |= a.tile;
+}
+
+// v_min3_f32 / v_max3_f32 on operands known to be numbers
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 template <int MODE>
@@ -634,9 +646,11 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 
         // ---- box of the wave's range (input of the octree replay): skipped points stay out of it ----
         if (__ballot(!(o0.seen && o1.seen && o2.seen && o3.seen)) == 0ull) {
-            bn0 = fminf(fminf(bn0, fminf(cx.x, cx.y)), fminf(cx.z, cx.w)); bx0 = fmaxf(fmaxf(bx0, fmaxf(cx.x, cx.y)), fmaxf(cx.z, cx.w));
-            bn1 = fminf(fminf(bn1, fminf(cy.x, cy.y)), fminf(cy.z, cy.w)); bx1 = fmaxf(fmaxf(bx1, fmaxf(cy.x, cy.y)), fmaxf(cy.z, cy.w));
-            bn2 = fminf(fminf(bn2, fminf(cz.x, cz.y)), fminf(cz.z, cz.w)); bx2 = fmaxf(fmaxf(bx2, fmaxf(cz.x, cz.y)), fmaxf(cz.z, cz.w));
+            // (all twelve coordinates are finite here; written as instructions because fminf / fmaxf make the
+            // compiler quiet every operand first, which costs more than the minimum itself)
+            bn0 = min3f(min3f(bn0, cx.x, cx.y), cx.z, cx.w); bx0 = max3f(max3f(bx0, cx.x, cx.y), cx.z, cx.w);
+            bn1 = min3f(min3f(bn1, cy.x, cy.y), cy.z, cy.w); bx1 = max3f(max3f(bx1, cy.x, cy.y), cy.z, cy.w);
+            bn2 = min3f(min3f(bn2, cz.x, cz.y), cz.z, cz.w); bx2 = max3f(max3f(bx2, cz.x, cz.y), cz.z, cz.w);
         } else {
             // a ragged last step or non-finite points: NaN is the neutral element of v_min / v_max
             const float nan = __uint_as_float(0x7fc00000u);
