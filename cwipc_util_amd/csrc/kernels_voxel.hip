@@ -83,8 +83,8 @@ constexpr int LOCAL_LEAVES = 64;               // leaves a workgroup can name lo
 // the finalize pass works on slices of a leaf's occupancy bitmap
 constexpr int RANK_THREADS = 256;
 constexpr int RANK_SEGS = 16;                  // a few leaves hold all the work: many slices per leaf for enough workgroups
-constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 308
-constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 5
+constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 615
+constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 3
 constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
 // Offsets are summed with a per-point bias so that the packed sums never borrow.  fl(f * inv_leaf)
 // may land |g| * 2^-23 voxels away from f / leaf, so an offset lies in [-|g| / 2, 2^22 + |g| / 2] units:
@@ -1379,22 +1379,6 @@ __global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWor
 // Sort-free output order for the octree path: leaves in Morton order of their final keys,
 // cells in ascending index inside a leaf = rank of a bit in the occupancy bitmaps.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ bool leaf_morton(const VoxWork &W, unsigned long long lp, int depth, unsigned long long &code) {
-    long long lk[3];
-    bool bad = false;
-    for (int a = 0; a < 3; a++) {
-        const long long shift = (long long)(((unsigned long long)W.ctrl[C_SHIFT + 2 * a + 1] << 32) | W.ctrl[C_SHIFT + 2 * a]);
-        lk[a] = (long long)unpack_leaf(lp, a) + shift;
-        if (lk[a] < 0 || lk[a] >= ((long long)1 << depth)) bad = true;
-    }
-    code = 0;
-    for (int b = depth - 1; b >= 0; b--) {
-        code = (code << 3) | (((unsigned long long)(lk[0] >> b) & 1) << 2) | (((unsigned long long)(lk[1] >> b) & 1) << 1) |
-               ((unsigned long long)(lk[2] >> b) & 1);
-    }
-    return !bad;
-}
-
 __device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W, unsigned long long lp, uint32_t key, uint32_t r,
                                             float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
     ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(record_ptr(W, key));
@@ -1435,61 +1419,96 @@ __device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W
 __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, VoxWork W, uint32_t leaf_cap, uint32_t m_or_cap, int speculative,
                                                                  uint32_t *order, float *__restrict__ ox, float *__restrict__ oy,
                                                                  float *__restrict__ oz, uint32_t *__restrict__ ow) {
+    // A workgroup's life is a chain of dependent memory round trips (it handles some sixty cells), so
+    // everything that does not depend on loaded data is requested at once, up front: control words, this
+    // leaf, every leaf's key and slice counts, the slice's bitmap words.  The cells in rank order go
+    // through LDS, not through global memory (unless a slice has more than RANK_LDS_CELLS of them).
+    constexpr uint32_t RANK_LDS_CELLS = 2048;
     __shared__ uint32_t wave_tot[RANK_THREADS / 64];
-    __shared__ uint32_t s_base;
-    uint32_t m = m_or_cap;
-    if (speculative) {
-        m = W.ctrl[C_COUNT];
-        if (W.ctrl[C_ERR] != 0u || m > m_or_cap || m == 0u) return;
-    }
+    __shared__ uint32_t s_cells[RANK_LDS_CELLS];
     const uint32_t p = blockIdx.x / RANK_SEGS, seg = blockIdx.x % RANK_SEGS;
-    const unsigned long long lp = W.leaf_keys[p];
-    if (lp == 0ull) return;
-    const int depth = (int)W.ctrl[C_DEPTH];
-    unsigned long long mine;
-    if (depth > 14 || !leaf_morton(W, lp, depth, mine)) {
-        if (threadIdx.x == 0) atomicOr(&W.ctrl[C_ERR], depth > 14 ? ERR_DEPTH : ERR_LEAF_RANGE);
-        return;   // the host cleans up through the occupied list
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *bm = W.bitmaps + (size_t)p * BITWORDS;
     const int w_lo = (int)seg * SEG_WORDS;
     const int w_hi = min(w_lo + SEG_WORDS, BITWORDS);
+    // ---- loads ----
+    const uint32_t c_count = W.ctrl[C_COUNT], c_err = W.ctrl[C_ERR], c_depth = W.ctrl[C_DEPTH];
+    uint32_t c_shift[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) c_shift[i] = W.ctrl[C_SHIFT + i];
+    const unsigned long long lp = W.leaf_keys[p];
+    uint32_t words[WORDS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < WORDS_PER_THREAD; i++) {
+        const int w = w_lo + threadIdx.x * WORDS_PER_THREAD + i;
+        words[i] = bm[min(w, w_hi - 1)];
+    }
+    const uint32_t q0 = min((uint32_t)threadIdx.x, leaf_cap - 1u);   // this thread's leaf in the first round of the loop below
+    const unsigned long long lq0 = W.leaf_keys[q0];
+    uint4 sc0[RANK_SEGS / 4];
+    {
+        const uint4 *sc = reinterpret_cast<const uint4 *>(W.seg_count + (size_t)q0 * RANK_SEGS);
+#pragma unroll
+        for (int v = 0; v < RANK_SEGS / 4; v++) sc0[v] = sc[v];
+    }
+    const uint32_t own_earlier = threadIdx.x < seg ? W.seg_count[p * RANK_SEGS + threadIdx.x] : 0u;   // seg <= RANK_SEGS <= RANK_THREADS
+    // ---- what they say ----
+    uint32_t m = m_or_cap;
+    if (speculative) {
+        m = c_count;
+        if (c_err != 0u || m > m_or_cap || m == 0u) return;
+    }
+    if (lp == 0ull) return;
+    const int depth = (int)c_depth;
+    long long shift[3];
+    for (int a = 0; a < 3; a++) shift[a] = (long long)(((unsigned long long)c_shift[2 * a + 1] << 32) | c_shift[2 * a]);
+    const auto morton = [&](unsigned long long leaf, unsigned long long &code) {
+        long long lk[3];
+        bool bad = false;
+        for (int a = 0; a < 3; a++) {
+            lk[a] = (long long)unpack_leaf(leaf, a) + shift[a];
+            if (lk[a] < 0 || lk[a] >= ((long long)1 << depth)) bad = true;
+        }
+        code = 0;
+        for (int b = depth - 1; b >= 0; b--) {
+            code = (code << 3) | (((unsigned long long)(lk[0] >> b) & 1) << 2) | (((unsigned long long)(lk[1] >> b) & 1) << 1) |
+                   ((unsigned long long)(lk[2] >> b) & 1);
+        }
+        return !bad;
+    };
+    unsigned long long mine;
+    if (depth > 14 || !morton(lp, mine)) {
+        if (threadIdx.x == 0) atomicOr(&W.ctrl[C_ERR], depth > 14 ? ERR_DEPTH : ERR_LEAF_RANGE);
+        return;   // the host cleans up through the occupied list
+    }
     // ---- base: cells of the leaves that come first, plus this leaf's cells in earlier slices ----
-    uint32_t before = 0;
+    uint32_t before = own_earlier;
     for (uint32_t q = threadIdx.x; q < leaf_cap; q += RANK_THREADS) {
-        const unsigned long long lq = W.leaf_keys[q];
-        unsigned long long other;
-        if (lq != 0ull && q != p && leaf_morton(W, lq, depth, other) && other < mine) {
+        unsigned long long lq = lq0;
+        uint4 scq[RANK_SEGS / 4];
+#pragma unroll
+        for (int v = 0; v < RANK_SEGS / 4; v++) scq[v] = sc0[v];
+        if (q >= RANK_THREADS) {   // more leaves than threads (rare): the later rounds load as they go
+            lq = W.leaf_keys[q];
             const uint4 *sc = reinterpret_cast<const uint4 *>(W.seg_count + (size_t)q * RANK_SEGS);
 #pragma unroll
-            for (int v = 0; v < RANK_SEGS / 4; v++) {
-                const uint4 t = sc[v];
-                before += t.x + t.y + t.z + t.w;
-            }
+            for (int v = 0; v < RANK_SEGS / 4; v++) scq[v] = sc[v];
+        }
+        unsigned long long other;
+        if (lq != 0ull && q != p && morton(lq, other) && other < mine) {
+#pragma unroll
+            for (int v = 0; v < RANK_SEGS / 4; v++) before += scq[v].x + scq[v].y + scq[v].z + scq[v].w;
         }
     }
-    // earlier slices may already have been cleaned by their own workgroups, so their cells are
-    // counted from the per-slice totals K1 accumulated, not from the bitmaps
-    for (uint32_t sg = threadIdx.x; sg < seg; sg += RANK_THREADS) before += W.seg_count[p * RANK_SEGS + sg];
+    // (earlier slices may already have been cleaned by their own workgroups, so their cells are counted
+    // from the per-slice totals K1 accumulated, not from the bitmaps)
     for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
-    if (lane == 0) wave_tot[wave] = before;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < RANK_THREADS / 64; w++) t += wave_tot[w];
-        s_base = t;
-    }
-    __syncthreads();
-    const uint32_t base = s_base;
-    __syncthreads();
     // ---- ranks inside the slice: each lane owns WORDS_PER_THREAD consecutive bitmap words ----
-    uint32_t words[WORDS_PER_THREAD];
     uint32_t mycount = 0;
 #pragma unroll
     for (int i = 0; i < WORDS_PER_THREAD; i++) {
         const int w = w_lo + threadIdx.x * WORDS_PER_THREAD + i;
-        words[i] = w < w_hi ? bm[w] : 0u;
+        if (w >= w_hi) words[i] = 0u;
         mycount += __popc(words[i]);
     }
     uint32_t inc = mycount;
@@ -1497,15 +1516,22 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
         const uint32_t t = __shfl_up(inc, off, 64);
         if (lane >= off) inc += t;
     }
-    if (lane == 63) wave_tot[wave] = inc;
+    __shared__ uint32_t wave_cells[RANK_THREADS / 64];
+    if (lane == 0) wave_tot[wave] = before;
+    if (lane == 63) wave_cells[wave] = inc;
     __syncthreads();
-    uint32_t wbase = 0, total = 0;
+    uint32_t base = 0, wbase = 0, total = 0;
     for (int w = 0; w < RANK_THREADS / 64; w++) {
-        if (w < wave) wbase += wave_tot[w];
-        total += wave_tot[w];
+        base += wave_tot[w];
+        if (w < wave) wbase += wave_cells[w];
+        total += wave_cells[w];
     }
-    uint32_t rank = base + wbase + inc - mycount;
-    // phase 1: write the slice's cells in rank order (stores only: no dependent loads in this serial part)
+    // phase 1: the slice's cells in rank order, the bitmap words cleaned
+    uint32_t local = wbase + inc - mycount;
+    if (base + total > m) {
+        if (threadIdx.x == 0) atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+    }
+    const bool in_lds = total <= RANK_LDS_CELLS;
 #pragma unroll
     for (int i = 0; i < WORDS_PER_THREAD; i++) {
         uint32_t bits = words[i];
@@ -1514,16 +1540,17 @@ __global__ void __launch_bounds__(RANK_THREADS) rank_emit_kernel(VoxParams P, Vo
         while (bits) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            if (rank < m) order[rank] = (p << CELL_BITS) | (uint32_t)(w * 32 + b);
-            else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
-            rank++;
+            const uint32_t cell = (p << CELL_BITS) | (uint32_t)(w * 32 + b);
+            if (in_lds) s_cells[local] = cell;
+            else if (base + local < m) order[base + local] = cell;
+            local++;
         }
     }
-    __syncthreads();   // this workgroup's order[] stores are visible to its own lanes from here on
+    __syncthreads();   // (this workgroup's order[] stores are visible to its own lanes from here on)
     // phase 2: gather, emit and clean, one cell per lane
     for (uint32_t i = threadIdx.x; i < total; i += RANK_THREADS) {
         const uint32_t r = base + i;
-        if (r < m) emit_record(P, W, lp, __hip_atomic_load(&order[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r, ox, oy, oz, ow);
+        if (r < m) emit_record(P, W, lp, in_lds ? s_cells[i] : __hip_atomic_load(&order[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), r, ox, oy, oz, ow);
     }
 }
 
