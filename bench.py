@@ -104,8 +104,8 @@ def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 12.0)
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--npoints", type=int, default=NPOINTS_ARG)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
