@@ -116,7 +116,7 @@ enum {
     C_ERR = 0, C_COUNT = 1, C_DEPTH = 2, C_EVENTS = 3, C_SHIFT = 4 /* 3 x int64 */, C_MINB = 10, C_DIVB = 13,
     C_FALLBACK = 16,   // runs that found the workgroup table full and went to the global records one lane at a time
     C_MAXLOAD = 17,    // fullest workgroup table (entries)
-    C_SEQ = 31,        // host copy only: sequence number of the pass, written last (the host polls it)
+    C_SEQ = 31,        // number of published words (the host copy carries the pass's sequence number in the upper half of each 64-bit word)
     C_WORDS = 32
 };
 
@@ -1074,14 +1074,18 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 // ---------------------------------------------------------------------------
 // K2: octree bounding-box replay / global grid box
 // ---------------------------------------------------------------------------
-// Results straight into the host's pinned words, the pass's sequence number last: the host polls that
-// word instead of waiting for the stream (a blocking stream wait wakes up several microseconds late).
+// Results straight into the host's pinned words: the host polls them instead of waiting for the stream
+// (a blocking stream wait wakes up several microseconds late).
+// Every control word travels as one 64-bit store with the sequence number in its upper half, so the host
+// can tell word by word what has arrived: no release fence (a system-scope release writes back the whole
+// L2, which K1 has just filled with dirty records) and no second store behind it.
 __device__ __forceinline__ void publish(const uint32_t *ctrl, uint32_t *host_out, uint32_t seq) {
     const int tid = threadIdx.x;
-    if (tid < C_SEQ) host_out[tid] = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&host_out[C_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < C_SEQ) {
+        const uint32_t v = __hip_atomic_load(&ctrl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_out) + tid, ((unsigned long long)seq << 32) | v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Growth of pcl::octree::OctreePointCloud's box is sequential in input order, but a range
@@ -1910,7 +1914,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
         const uint32_t seq = ++ws.seq ? ws.seq : ++ws.seq;
-        c.host_words[C_SEQ] = 0;
+        for (int i = 0; i < C_SEQ; i++) c.host_words[2 * i + 1] = 0;   // the tags of the words the replay kernel will publish
         // control words, leaf table, slice counts: this pass's block (zeroed by the previous pass's replay kernel)
         const int blk = ws.parity;
         char *head = (char *)ws.head + (size_t)blk * ws.head_bytes, *next_head = (char *)ws.head + (size_t)(1 - blk) * ws.head_bytes;
@@ -1978,26 +1982,38 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         }
         // wait for the replay kernel's sequence number in pinned memory (a few hundred microseconds of
         // polling at most, then the ordinary stream wait, which also reports launch failures)
-        if (ok && !profiling_enabled()) {
-            volatile uint32_t *flag = c.host_words + C_SEQ;
-            const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+        uint32_t hw[C_SEQ];   // the published control words
+        {
+            volatile unsigned long long *words = reinterpret_cast<volatile unsigned long long *>(c.host_words);
+            const auto take = [&]() {   // true when every word carries this pass's tag
+                for (int i = 0; i < C_SEQ; i++) {
+                    const unsigned long long w = words[i];
+                    if ((uint32_t)(w >> 32) != seq) return false;
+                    hw[i] = (uint32_t)w;
+                }
+                return true;
+            };
             bool seen = false;
-            for (int spin = 0;; spin++) {
-                if (*flag == seq) { seen = true; break; }
-                if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;
-                __builtin_ia32_pause();
+            if (ok && !profiling_enabled()) {
+                const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+                for (int spin = 0;; spin++) {
+                    if ((uint32_t)(words[C_COUNT] >> 32) == seq && take()) { seen = true; break; }
+                    if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;
+                    __builtin_ia32_pause();
+                }
             }
-            if (!seen) ok = c.sync() && ok;
+            if (!seen) {
+                ok = c.sync() && ok;
+                if (ok && !take()) { ok = false; cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the replay kernel did not report"); }
+            }
             std::atomic_thread_fence(std::memory_order_acquire);
-        } else {
-            ok = c.sync() && ok;
         }
         if (!ok) { hip_failed(launch_err != hipSuccess ? launch_err : hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
-        uint32_t err = c.host_words[C_ERR];
+        uint32_t err = hw[C_ERR];
         {
             // adapt the workgroup size for the next call
-            const uint32_t fallbacks = c.host_words[C_FALLBACK], maxload = c.host_words[C_MAXLOAD];
+            const uint32_t fallbacks = hw[C_FALLBACK], maxload = hw[C_MAXLOAD];
             if (ws.incoherent) {
                 // nothing to adapt: this kind of cloud defeats the table whatever its size
             } else if (ws.shrink >= 2 && (size_t)fallbacks * 2 > n) {
@@ -2013,7 +2029,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 ws.calm = 0;
             }
         }
-        const uint32_t m = c.host_words[C_COUNT] < P.list_cap ? c.host_words[C_COUNT] : P.list_cap;
+        const uint32_t m = hw[C_COUNT] < P.list_cap ? hw[C_COUNT] : P.list_cap;
         std::shared_ptr<DeviceSoA> dst;
         unsigned long long *keys_in = nullptr, *keys_out = nullptr;
         uint32_t *vals_in = nullptr, *vals_out = nullptr;
@@ -2049,7 +2065,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!err && m && !leaf_split) {
             // plain grid, the usual case: output order from a bitmap over the VoxelGrid index space, no sort;
             // like the octree variant the call returns with these passes in flight
-            const unsigned long long cells = (unsigned long long)c.host_words[C_DIVB] * c.host_words[C_DIVB + 1] * c.host_words[C_DIVB + 2];
+            const unsigned long long cells = (unsigned long long)hw[C_DIVB] * hw[C_DIVB + 1] * hw[C_DIVB + 2];
             unsigned long long bitmap_max = GRID_BITMAP_MAX_CELLS;
             if (const char *e = getenv("CWIPC_GRID_BITMAP_MAX")) bitmap_max = strtoull(e, nullptr, 10);   // test knob: force the sort path
             if (cells <= bitmap_max) {
