@@ -270,6 +270,24 @@ void *ThreadCtx::staging(size_t bytes) {
     return pinned;
 }
 
+void *ThreadCtx::device_scratch(size_t bytes) {
+    if (bytes <= scratch_bytes) return scratch;
+    if (scratch) {
+        (void)hipStreamSynchronize(stream);   // kernels of earlier calls may still use the old block
+        (void)hipFree(scratch);
+    }
+    scratch = nullptr;
+    scratch_bytes = 0;
+    const size_t want = size_class(bytes < 65536 ? 65536 : bytes);
+    if (hipMalloc(&scratch, want) != hipSuccess) {
+        hip_failed(hipGetLastError(), "hipMalloc(scratch)", __FILE__, __LINE__);
+        scratch = nullptr;
+        return nullptr;
+    }
+    scratch_bytes = want;
+    return scratch;
+}
+
 bool ThreadCtx::sync() {
     CW_HIP_TRY(hipStreamSynchronize(stream));
     if (profiling_enabled()) profile_collect();
@@ -285,6 +303,7 @@ ThreadCtx::~ThreadCtx() {
     if (pinned) (void)hipHostFree(pinned);
     if (host_words) (void)hipHostFree(host_words);
     if (dev_words) (void)hipFree(dev_words);
+    if (scratch) (void)hipFree(scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -326,6 +345,25 @@ void DeviceSoA::mark_pending(hipStream_t producer) {
         (void)hipStreamSynchronize(producer);
         if (ready) { event_put(ready); ready = nullptr; }
     }
+}
+
+void DeviceSoA::note_reader(hipStream_t consumer) const {
+    hipEvent_t e = event_get();
+    if (!e || hipEventRecord(e, consumer) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(consumer);   // without an event: let the reader finish now
+        if (e) event_put(e);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(readers_mutex);
+    for (auto &r : readers) {
+        if (r.first == consumer) {   // a later event on the same stream covers the earlier one
+            event_put(r.second);
+            r.second = e;
+            return;
+        }
+    }
+    readers.emplace_back(consumer, e);
 }
 
 // ---------------------------------------------------------------------------

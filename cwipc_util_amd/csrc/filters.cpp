@@ -5,6 +5,9 @@
 // logs an ERROR and returns NULL.
 #include "internal.hpp"
 
+#include <atomic>
+#include <chrono>
+
 #include <algorithm>
 #include <cstring>
 
@@ -55,34 +58,55 @@ cwipc_pointcloud *wrap(std::shared_ptr<DeviceSoA> planes, uint64_t timestamp, fl
 // output planes have room for every input point (the kept count is known only when the kernels are
 // done; the scan kernel writes it into the thread's pinned words); a result that uses less than a
 // sixteenth of that room is copied into a buffer of its own size.
-std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p) {
+std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, bool may_return_early) {
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     size_t n = src.npoints;
     if (n == 0) return soa_alloc(0);
     size_t nb = k::compact_blocks(n);
-    uint32_t *counts = (uint32_t *)pool_alloc(nb * sizeof(uint32_t));
+    uint32_t *counts = (uint32_t *)c.device_scratch(nb * sizeof(uint32_t));
     auto dst = soa_alloc(n);
-    if (!counts || !dst) { pool_free(counts); return nullptr; }
-    c.host_words[0] = 0xffffffffu;
+    if (!counts || !dst) return nullptr;
+    // the scan kernel publishes the kept count with this tag in the upper half of the first 64-bit pinned word
+    const uint32_t tag = ++c.tag ? c.tag : ++c.tag;
+    volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(c.host_words);
+    *word = 0ull;
     k::compact_count(src, p, counts, c.stream);
-    k::compact_scan(counts, nb, c.host_words, c.stream);   // total -> pinned host word
+    k::compact_scan(counts, nb, reinterpret_cast<unsigned long long *>(c.host_words), tag, c.stream);
     k::compact_scatter(src, p, counts, *dst, c.stream);
-    const bool ok = c.sync();
-    pool_free(counts);
-    if (!ok) {
+    bool ok = hipGetLastError() == hipSuccess;
+    // The count is there when the scan kernel is done; the scatter kernel behind it needs no more attention
+    // from the host, so a caller that allows it gets the result back with that kernel still running.
+    bool seen = false;
+    if (ok && may_return_early && !profiling_enabled()) {
+        const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+        for (int spin = 0;; spin++) {
+            if ((uint32_t)(*word >> 32) == tag) { seen = true; break; }
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) ok = c.sync() && ok;
+    if (!ok || (uint32_t)(*word >> 32) != tag) {
         hip_failed(hipGetLastError(), "compaction", __FILE__, __LINE__);
         return nullptr;
     }
-    const size_t kept = c.host_words[0];
+    const size_t kept = (uint32_t)*word;
     if (kept > n) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip", "compaction: inconsistent count");
+        if (seen) (void)c.sync();
         return nullptr;
     }
     if (kept * 16 >= n) {
         dst->npoints = kept;   // the planes keep their spacing (stride), only the count shrinks
+        if (seen) {
+            dst->mark_pending(c.stream);
+            src.note_reader(c.stream);   // the scatter kernel is still reading the input
+        }
         return dst;
     }
+    if (seen && !c.sync()) return nullptr;   // the copy below reads what the scatter kernel writes, then `dst` goes back to the pool
     auto small = soa_alloc(kept);
     if (!small) return nullptr;
     if (kept) {
@@ -111,7 +135,7 @@ extern "C" cwipc_pointcloud *cwipc_tilefilter(cwipc_pointcloud *pc, int tile) {
     k::Predicate p{};
     p.mode = 0;
     p.tile = tile;
-    return wrap(compact(*src, p), pc->timestamp(), pc->cellsize());
+    return wrap(compact(*src, p, true), pc->timestamp(), pc->cellsize());
 }
 
 // reference python/cwipc/registration/util.py:98-112 (numpy boolean-mask selection)
@@ -123,7 +147,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_tilefilter_masked(cwipc_pointcloud *pc, i
     k::Predicate p{};
     p.mode = 2;
     p.tile = mask & 0xff;
-    return wrap(compact(*src, p), pc->timestamp(), pc->cellsize());
+    return wrap(compact(*src, p, true), pc->timestamp(), pc->cellsize());
 }
 
 // reference src/cwipc_filters.cpp:333-360
@@ -135,7 +159,7 @@ extern "C" cwipc_pointcloud *cwipc_crop(cwipc_pointcloud *pc, float bbox[6]) {
     k::Predicate p{};
     p.mode = 1;
     memcpy(p.bbox, bbox, 6 * sizeof(float));
-    return wrap(compact(*src, p), pc->timestamp(), pc->cellsize());
+    return wrap(compact(*src, p, true), pc->timestamp(), pc->cellsize());
 }
 
 // reference src/cwipc_filters.cpp:308-331

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <memory>
+#include <utility>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,6 +79,10 @@ struct ThreadCtx {
     size_t pinned_bytes = 0;
     uint32_t *host_words = nullptr;   // 64 pinned 32-bit words for small read-backs
     void *dev_words = nullptr;        // 64 device words
+    void *scratch = nullptr;          // device scratch of this thread's calls (block counts of a compaction): work on one
+    size_t scratch_bytes = 0;         //   stream is ordered, so the next call may overwrite it while nobody else can
+    uint32_t tag = 0;                 // sequence number of the last value a kernel published into host_words
+    void *device_scratch(size_t bytes);
     bool ensure();                    // create the stream etc. for the current device
     void *staging(size_t bytes);      // pinned buffer of at least `bytes`
     bool sync();
@@ -133,6 +138,11 @@ struct DeviceSoA {
     void wait_host() const {                            // for consumers outside the library's streams
         if (ready) (void)hipEventSynchronize(ready);
     }
+    // The other direction: a call that returned with a kernel still READING these planes leaves an event
+    // here (one per stream, the latest), and the planes are not given back to the pool before it.
+    mutable std::mutex readers_mutex;
+    mutable std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
+    void note_reader(hipStream_t consumer) const;
     float *x() const { return (float *)base; }
     float *y() const { return (float *)base + stride; }
     float *z() const { return (float *)base + 2 * stride; }
@@ -141,6 +151,10 @@ struct DeviceSoA {
         if (ready) {
             (void)hipEventSynchronize(ready);   // normally long complete
             event_put(ready);
+        }
+        for (auto &r : readers) {
+            (void)hipEventSynchronize(r.second);
+            event_put(r.second);
         }
         if (base) pool_free(base);
     }
@@ -240,7 +254,7 @@ struct Predicate {
 size_t compact_blocks(size_t n);
 void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, hipStream_t s);
 // Exclusive scan of block_counts in place; total written to *total_dev.
-void compact_scan(uint32_t *block_counts, size_t nblocks, uint32_t *total_dev, hipStream_t s);
+void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *total_host, uint32_t tag, hipStream_t s);
 // Pass 2: scatter kept points to dst in input order.
 void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s);
 
@@ -278,6 +292,8 @@ bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *th
 std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr);
 
 // Generic stable compaction driver used by tilefilter / crop / masked filter.
-std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p);
+// may_return_early: the call may come back with the scatter kernel still running (the result carries a
+// `ready` event); only for predicates that refer to nothing the caller frees afterwards.
+std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, bool may_return_early = false);
 
 }  // namespace cwipc_amd

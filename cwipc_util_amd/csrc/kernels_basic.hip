@@ -156,7 +156,10 @@ __global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const 
 
 // Exclusive scan of up to millions of block counts by ONE workgroup of 1024 lanes
 // (the count array is tiny: N/4096 entries).
-__global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict__ counts, size_t nblocks, uint32_t *__restrict__ total) {
+// The total goes to a pinned host word with `tag` in its upper half (one 64-bit store, no fence): the
+// host polls for the tag instead of waiting for the stream.
+__global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict__ counts, size_t nblocks, unsigned long long *__restrict__ total,
+                                                            uint32_t tag) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict
         if (threadIdx.x == 1023) carry = c + wave_base + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) __hip_atomic_store(total, ((unsigned long long)tag << 32) | carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
@@ -263,8 +266,8 @@ void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_cou
               src.npoints, block_counts);
 }
 
-void compact_scan(uint32_t *block_counts, size_t nblocks, uint32_t *total_dev, hipStream_t s) {
-    CW_LAUNCH("compact_scan", compact_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_dev);
+void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *total_host, uint32_t tag, hipStream_t s) {
+    CW_LAUNCH("compact_scan", compact_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_host, tag);
 }
 
 void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s) {

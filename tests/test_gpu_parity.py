@@ -807,6 +807,44 @@ def test_results_outlive_the_thread_that_made_them(gpu, oracle, synth):
             assert 0 < out.count() <= len(exp)
 
 
+def test_input_freed_while_its_filter_result_is_pending(gpu, oracle, synth):
+    """cwipc_tilefilter / cwipc_crop return with their last kernel still reading the input.  Freeing the input
+    right away, and filling the memory it gives back with other clouds (here and on other threads), must
+    not change the result."""
+    import threading, gc
+    pts, cs = synth(300000)
+    exp = oracle.tilefilter(pts, 1)
+    exp_crop = oracle.crop(pts, [-0.1, 0.1, 0.0, 1.0, -1, 1])
+    other = pts.copy()
+    other['x'] += 5.0
+    other['tile'] = 1
+    stop, errors = threading.Event(), []
+
+    def churn():   # another thread grabbing and dirtying pool blocks of the same size class
+        try:
+            while not stop.is_set():
+                gpu.cwipc_colormap(make_cloud(gpu, other, cs), 0xffffffff, 0x01020304).count()
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=churn)
+    t.start()
+    try:
+        for i in range(40):
+            pc = make_cloud(gpu, pts, cs)
+            gpu.cwipc_hip_upload(pc, drop_host_copy=True)
+            out = gpu.cwipc_tilefilter(pc, 1) if i % 2 == 0 else gpu.cwipc_crop(pc, [-0.1, 0.1, 0.0, 1.0, -1, 1])
+            pc.free()
+            del pc
+            filler = make_cloud(gpu, other, cs)   # same size class: gets the block the input gave back
+            gpu.cwipc_hip_upload(filler)
+            assert same(out.get_numpy_array(), exp if i % 2 == 0 else exp_crop)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
