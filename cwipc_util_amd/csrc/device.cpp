@@ -289,7 +289,10 @@ void *ThreadCtx::device_scratch(size_t bytes) {
 }
 
 bool ThreadCtx::sync() {
-    CW_HIP_TRY(hipStreamSynchronize(stream));
+    const hipError_t e = hipStreamSynchronize(stream);
+    for (void *p : deferred) pool_free(p);   // (their kernels are done, or the stream is beyond help)
+    deferred.clear();
+    if (e != hipSuccess) return hip_failed(e, "hipStreamSynchronize(stream)", __FILE__, __LINE__);
     if (profiling_enabled()) profile_collect();
     return true;
 }
@@ -304,6 +307,7 @@ ThreadCtx::~ThreadCtx() {
     if (host_words) (void)hipHostFree(host_words);
     if (dev_words) (void)hipFree(dev_words);
     if (scratch) (void)hipFree(scratch);
+    for (void *p : deferred) pool_free(p);
 }
 
 // ---------------------------------------------------------------------------

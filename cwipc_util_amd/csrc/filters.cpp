@@ -363,11 +363,14 @@ namespace {
 // The inner overload (:181-211): SOR over one cloud's planes.
 std::shared_ptr<DeviceSoA> sor_once(const DeviceSoA &src, int k, float stddev_mul) {
     if (src.npoints == 0) return soa_alloc(0);
-    float *dist = (float *)pool_alloc(src.npoints * sizeof(float));
+    // d_i, then the threshold (on the device: nothing is read back in between), then the compaction, whose
+    // wait is the only one after the k-NN grid has been set up
+    float *dist = (float *)pool_alloc(src.npoints * sizeof(float) + 256);
     if (!dist) return nullptr;
+    double *thr_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(dist) + ((src.npoints * sizeof(float) + 127) & ~(size_t)127));
     std::shared_ptr<DeviceSoA> out;
-    double thr = 0;
-    if (sor_mean_distances(src, k, dist) && sor_threshold(dist, src.npoints, stddev_mul, &thr)) out = sor_select(src, dist, thr);
+    if (sor_mean_distances(src, k, dist) && sor_threshold_device(dist, src.npoints, stddev_mul, thr_dev)) out = sor_select(src, dist, 0.0, thr_dev);
+    else (void)tctx().sync();
     pool_free(dist);
     return out;
 }

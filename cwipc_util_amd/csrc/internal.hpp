@@ -83,6 +83,8 @@ struct ThreadCtx {
     size_t scratch_bytes = 0;         //   stream is ordered, so the next call may overwrite it while nobody else can
     uint32_t tag = 0;                 // sequence number of the last value a kernel published into host_words
     void *device_scratch(size_t bytes);
+    std::vector<void *> deferred;     // pool blocks whose last kernel may still run: given back at the next sync()
+    void free_later(void *pool_block) { if (pool_block) deferred.push_back(pool_block); }
     bool ensure();                    // create the stream etc. for the current device
     void *staging(size_t bytes);      // pinned buffer of at least `bytes`
     bool sync();
@@ -249,6 +251,7 @@ struct Predicate {
     float bbox[6];
     const float *dist;
     double thr;
+    const double *thr_dev;   // mode 3: device address of the threshold when a kernel computed it (thr is ignored then)
 };
 // Pass 1: per-block keep counts into block_counts[nblocks]; returns nblocks through the argument.
 size_t compact_blocks(size_t n);
@@ -288,8 +291,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
 bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist);
 // mean/stddev threshold from d_i exactly as pcl::StatisticalOutlierRemoval; result in *thr.
 bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *thr);
+// The same on the device, nothing read back: *thr_dev (device memory) receives the threshold.
+bool sor_threshold_device(const float *dev_dist, size_t n, float stddev_mul, double *thr_dev);
 // Stable compaction of points with !(d_i > thr).
-std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr);
+std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr, const double *thr_dev = nullptr);
 
 // Generic stable compaction driver used by tilefilter / crop / masked filter.
 // may_return_early: the call may come back with the scatter kernel still running (the result carries a

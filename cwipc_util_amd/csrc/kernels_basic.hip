@@ -84,13 +84,14 @@ struct PredArgs {
     float b0, b1, b2, b3, b4, b5;
     const float *dist;
     double thr;
+    const double *thr_dev;   // mode 3: the threshold, if a kernel computed it (else thr)
 };
 
 __device__ __forceinline__ bool keep_point(const PredArgs &p, float x, float y, float z, uint32_t w, size_t idx) {
     int t = (int)(w >> 24);
     if (p.mode == 0) return p.tile == 0 || p.tile == t;
     if (p.mode == 2) return (t & p.tile) != 0;
-    if (p.mode == 3) return !((double)p.dist[idx] > p.thr);   // fp32 d_i widened for the f64 compare
+    if (p.mode == 3) return !((double)p.dist[idx] > (p.thr_dev ? *p.thr_dev : p.thr));   // fp32 d_i widened for the f64 compare
     return p.b0 <= x && x < p.b1 && p.b2 <= y && y < p.b3 && p.b4 <= z && z < p.b5;
 }
 
@@ -256,6 +257,7 @@ static PredArgs to_args(const Predicate &p) {
     a.b3 = p.bbox[3]; a.b4 = p.bbox[4]; a.b5 = p.bbox[5];
     a.dist = p.dist;
     a.thr = p.thr;
+    a.thr_dev = p.thr_dev;
     return a;
 }
 

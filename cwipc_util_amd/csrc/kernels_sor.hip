@@ -14,6 +14,7 @@
 // of cells around its point and keeps the k+1 smallest distances in LDS; a shell
 // radius r proves exactness once the (k+1)-th distance is <= r*h.
 #include "internal.hpp"
+#include <vector>
 
 #include <cstdlib>
 #include <cstring>
@@ -446,11 +447,50 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
             CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, sorted, n, starts, counts, k, dev_dist);
         }
     }
-    ok = c.sync() && ok;
-    pool_free(cursor);
-    cleanup();
-    if (!ok) hip_failed(hipGetLastError(), "sor k-NN", __FILE__, __LINE__);
+    // no wait here: every caller has one further down (the compaction, a copy to the host), and the
+    // temporaries go back to the pool there
+    ok = hipGetLastError() == hipSuccess && ok;
+    c.free_later(cursor); c.free_later(counts); c.free_later(fill); c.free_later(cell_id); c.free_later(sorted); c.free_later(scan_tmp);
+    if (!ok) {
+        hip_failed(hipGetLastError(), "sor k-NN", __FILE__, __LINE__);
+        (void)c.sync();
+    }
     return ok;
+}
+
+// mean, variance and threshold from the 1024 partial sums: a pairwise tree (s[i] = s[2i] + s[2i+1], ten
+// levels), the order the host version (sor_threshold) follows too, then the same f64 expressions
+__global__ void __launch_bounds__(1024) stats_final_kernel(const double *__restrict__ partial, size_t n, float stddev_mul, double *__restrict__ thr) {
+    __shared__ double s[1024], q[1024];
+    s[threadIdx.x] = partial[2 * threadIdx.x];
+    q[threadIdx.x] = partial[2 * threadIdx.x + 1];
+    __syncthreads();
+    for (unsigned width = 512; width >= 1; width >>= 1) {
+        double a = 0, b = 0;
+        if (threadIdx.x < width) { a = s[2 * threadIdx.x] + s[2 * threadIdx.x + 1]; b = q[2 * threadIdx.x] + q[2 * threadIdx.x + 1]; }
+        __syncthreads();
+        if (threadIdx.x < width) { s[threadIdx.x] = a; q[threadIdx.x] = b; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double sum = s[0], sq_sum = q[0];
+    const double valid = (double)n;
+    const double mean = sum / valid;
+    const double variance = (sq_sum - sum * sum / valid) / (valid - 1);
+    const double stddev = sqrt(variance);
+    *thr = mean + (double)stddev_mul * stddev;
+}
+
+bool sor_threshold_device(const float *dev_dist, size_t n, float stddev_mul, double *thr_dev) {
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return false;
+    const unsigned nb = 1024;
+    double *partial = (double *)pool_alloc(nb * 2 * sizeof(double));
+    if (!partial) return false;
+    CW_LAUNCH("sor_stats", stats_partial_kernel, dim3(nb), dim3(BLK), 0, c.stream, dev_dist, n, partial);
+    CW_LAUNCH("sor_stats_final", stats_final_kernel, dim3(1), dim3(1024), 0, c.stream, partial, n, stddev_mul, thr_dev);   // nb == 1024
+    c.free_later(partial);
+    return hipGetLastError() == hipSuccess;
 }
 
 bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *thr) {
@@ -465,8 +505,12 @@ bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *th
     ok = c.sync() && ok;
     pool_free(partial);
     if (!ok) return false;
-    double sum = 0, sq_sum = 0;
-    for (unsigned b = 0; b < nb; b++) { sum += h[2 * b]; sq_sum += h[2 * b + 1]; }
+    // pairwise tree over the partial sums, as stats_final_kernel does it
+    std::vector<double> s(nb), q(nb);
+    for (unsigned b = 0; b < nb; b++) { s[b] = h[2 * b]; q[b] = h[2 * b + 1]; }
+    for (unsigned width = nb / 2; width >= 1; width >>= 1)
+        for (unsigned i = 0; i < width; i++) { s[i] = s[2 * i] + s[2 * i + 1]; q[i] = q[2 * i] + q[2 * i + 1]; }
+    const double sum = s[0], sq_sum = q[0];
     // pcl::StatisticalOutlierRemoval: every point is "valid" here (finite input)
     double valid = (double)n;
     double mean = sum / valid;
@@ -476,12 +520,13 @@ bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *th
     return true;
 }
 
-std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr) {
+std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr, const double *thr_dev) {
     k::Predicate p{};
     p.mode = 3;
     p.dist = dev_dist;
     p.thr = thr;
-    return compact(src, p);
+    p.thr_dev = thr_dev;
+    return compact(src, p);   // (waits for its kernels: the caller frees dev_dist afterwards)
 }
 
 }  // namespace cwipc_amd
