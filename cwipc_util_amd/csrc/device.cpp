@@ -245,11 +245,18 @@ bool ThreadCtx::ensure() {
         (void)hipStreamSynchronize(stream);
         retire_stream(device, stream);
         stream = nullptr;
+        if (stream_alt) {
+            (void)hipStreamSynchronize(stream_alt);
+            retire_stream(device, stream_alt);
+            stream_alt = nullptr;
+        }
         if (dev_words) { (void)hipFree(dev_words); dev_words = nullptr; }
     }
     device = dev;
     stream = retired_stream_take(dev);
     if (!stream) CW_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream_alt = retired_stream_take(dev);
+    if (!stream_alt) CW_HIP_TRY(hipStreamCreateWithFlags(&stream_alt, hipStreamNonBlocking));
     if (!host_words) CW_HIP_TRY(hipHostMalloc((void **)&host_words, 64 * sizeof(uint32_t), hipHostMallocDefault));
     CW_HIP_TRY(hipMalloc(&dev_words, 64 * sizeof(uint32_t)));
     return true;
@@ -289,7 +296,11 @@ void *ThreadCtx::device_scratch(size_t bytes) {
 }
 
 bool ThreadCtx::sync() {
-    const hipError_t e = hipStreamSynchronize(stream);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (stream_alt) {
+        const hipError_t e2 = hipStreamSynchronize(stream_alt);
+        if (e == hipSuccess) e = e2;
+    }
     for (void *p : deferred) pool_free(p);   // (their kernels are done, or the stream is beyond help)
     deferred.clear();
     if (e != hipSuccess) return hip_failed(e, "hipStreamSynchronize(stream)", __FILE__, __LINE__);
@@ -302,6 +313,10 @@ ThreadCtx::~ThreadCtx() {
     if (stream) {
         (void)hipStreamSynchronize(stream);
         retire_stream(device, stream);
+    }
+    if (stream_alt) {
+        (void)hipStreamSynchronize(stream_alt);
+        retire_stream(device, stream_alt);
     }
     if (pinned) (void)hipHostFree(pinned);
     if (host_words) (void)hipHostFree(host_words);

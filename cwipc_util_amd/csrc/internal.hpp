@@ -75,6 +75,10 @@ struct PoolDeleter {
 struct ThreadCtx {
     int device = -1;
     hipStream_t stream = nullptr;
+    // A second stream: cwipc_downsample alternates between the two (with a workspace for each), so that the
+    // finalize kernel of one call, in flight when the call returns, does not hold up the first kernel of
+    // the next.  Everything else runs on `stream`; sync() waits for both.
+    hipStream_t stream_alt = nullptr;
     void *pinned = nullptr;       // staging for H2D/D2H of AoS points
     size_t pinned_bytes = 0;
     uint32_t *host_words = nullptr;   // 64 pinned 32-bit words for small read-backs

@@ -1691,6 +1691,7 @@ __global__ void __launch_bounds__(RANK_THREADS) clean_by_bitmap_kernel(VoxWork W
 // ---------------------------------------------------------------------------
 struct Workspace {
     int device = -1;
+    int cus = 0, cus_device = -1;   // compute units of the device the workspace was last used on
     uint32_t leaf_cap = 0;     // leaf hash capacity = number of grids (power of two)
     size_t list_cap = 0;
     size_t bbox_cap = 0;
@@ -1718,6 +1719,8 @@ struct Workspace {
     uint32_t *seg_count = nullptr;
     float *faces = nullptr;            // device copy of the threshold table
     float faces_host[3 * FACES];       // what the device copy holds
+    double faces_mn0[3] = {0, 0, 0};   //   ... and what it was computed from
+    double faces_res = 0;
     bool faces_valid = false;
     void release() {
         // also runs at thread exit, when the runtime may be gone: errors ignored
@@ -1740,7 +1743,22 @@ struct Workspace {
     ~Workspace() { release(); }
 };
 
-thread_local Workspace t_ws;
+// Two workspaces per thread, used by alternate calls, each with its own stream (ThreadCtx::stream / stream_alt):
+// a call's finalize kernel, still running when the call returns, works on grids the next call does not touch.
+thread_local Workspace t_ws[2];
+thread_local int t_ws_next = 0;
+
+// For the duration of a call: the thread's current stream is the one of the workspace in use.
+struct StreamOfWorkspace {
+    ThreadCtx &c;
+    bool swapped;
+    StreamOfWorkspace(ThreadCtx &ctx, int which) : c(ctx), swapped(which == 1 && ctx.stream_alt != nullptr) {
+        if (swapped) std::swap(c.stream, c.stream_alt);
+    }
+    ~StreamOfWorkspace() {
+        if (swapped) std::swap(c.stream, c.stream_alt);
+    }
+};
 
 constexpr size_t GRID_BYTES = (size_t)CELLS * RECORD_WORDS * 8;   // 20.1 MB per leaf grid
 constexpr size_t HEAD_CTRL_BYTES = 256;                           // C_WORDS words, padded
@@ -1835,14 +1853,24 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     const size_t n = src.npoints;
-    Workspace &ws = t_ws;
+    const int which = t_ws_next;
+    t_ws_next ^= 1;
+    Workspace &ws = t_ws[which];
+    StreamOfWorkspace on_its_stream(c, which);
+    src.wait_on(c.stream);   // (the caller ordered the thread's first stream behind the input's producer; this may be the second)
     if (n >= ((size_t)1 << 31)) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: more than 2^31 points");
         return nullptr;
     }
 
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus <= 0) cus = 256;
+    // (asked once per workspace and device: a runtime call on the way to the first launch is time the GPU waits)
+    if (ws.cus_device != current_device() || ws.cus <= 0) {
+        int cus_now = 0;
+        if (hipDeviceGetAttribute(&cus_now, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus_now <= 0) cus_now = 256;
+        ws.cus = cus_now;
+        ws.cus_device = current_device();
+    }
+    const int cus = ws.cus;
     // one persistent workgroup per CU; short clouds get fewer so that every wave has at least one step,
     // very large clouds get more (sequential) workgroups: the packed table needs < 65536 points per workgroup
     // Clouds with few points per voxel fill the workgroup table (2048 voxels): the previous calls of this
@@ -1876,11 +1904,12 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     const float octree_cellsize = (8 * 8) * cellsize;   // reference src/cwipc_filters.cpp:113-114
     P.res = (double)octree_cellsize;
     P.leaf_split = leaf_split ? 1 : 0;
-    const char *ablate = getenv("CWIPC_VOXEL_ABLATE");
-    P.ablate = ablate ? (uint32_t)atoi(ablate) : 0u;
+    static const uint32_t ablate_knob = []() { const char *e = getenv("CWIPC_VOXEL_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();   // debug knob, read once
+    P.ablate = ablate_knob;
 
     // ---- anchor and face thresholds (host, f64) ----
     float faces_host[3 * FACES];
+    double faces_key_mn0[3] = {0, 0, 0};
     memset(faces_host, 0, sizeof(faces_host));
     if (leaf_split) {
         if (!fetch_first_point(src, c)) return nullptr;
@@ -1901,8 +1930,17 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             P.ib[a] = (int)floor(P.mn0[a] / P.leaf_d);
             // the first point sits in leaf 1 of its box: cover faces 1 - FACE_BACK .. 1 - FACE_BACK + FACES - 1
             P.face_base[a] = 1 - FACE_BACK;
-            for (int i = 0; i < FACES; i++) faces_host[a * FACES + i] = leaf_threshold(P.mn0[a], P.res, P.face_base[a] + i);
         }
+        // the thresholds depend on the anchor's box and the resolution only: a stream of frames of one scene
+        // (and every repeat of a call) finds them in the workspace, host copy and device copy
+        const bool cached = ws.faces_valid && ws.faces_res == P.res && ws.faces_mn0[0] == P.mn0[0] && ws.faces_mn0[1] == P.mn0[1] && ws.faces_mn0[2] == P.mn0[2];
+        if (cached) {
+            memcpy(faces_host, ws.faces_host, sizeof(faces_host));
+        } else {
+            for (int a = 0; a < 3; a++)
+                for (int i = 0; i < FACES; i++) faces_host[a * FACES + i] = leaf_threshold(P.mn0[a], P.res, P.face_base[a] + i);
+        }
+        faces_key_mn0[0] = P.mn0[0]; faces_key_mn0[1] = P.mn0[1]; faces_key_mn0[2] = P.mn0[2];
     } else {
         for (int a = 0; a < 3; a++) P.ib[a] = 2;   // bricks of 64 voxels aligned to the voxel lattice
     }
@@ -1933,6 +1971,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 ok = hipMemcpyAsync(ws.faces, stage, sizeof(faces_host), hipMemcpyHostToDevice, c.stream) == hipSuccess;
                 memcpy(ws.faces_host, faces_host, sizeof(faces_host));
                 ws.faces_valid = ok;
+                ws.faces_res = P.res;
+                ws.faces_mn0[0] = faces_key_mn0[0]; ws.faces_mn0[1] = faces_key_mn0[1]; ws.faces_mn0[2] = faces_key_mn0[2];
             }
         }
         if (!ok) { hip_failed(hipGetLastError(), "voxel workspace setup", __FILE__, __LINE__); return nullptr; }
@@ -1978,6 +2018,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             if (spec_dst) {
                 hipLaunchKernelGGL(rank_emit_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, P, W, ws.leaf_cap, spec_cap, 1, ws.order,
                                    spec_dst->x(), spec_dst->y(), spec_dst->z(), spec_dst->rgbt());
+                // its `ready` event now, while the kernels run, not after the wait below: what the host does
+                // between the end of that wait and the next call's first launch is time the GPU stands still
+                spec_dst->mark_pending(c.stream);
             }
         }
         // wait for the replay kernel's sequence number in pinned memory (a few hundred microseconds of
@@ -2042,7 +2085,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             // the speculative finalize pass is doing the work: the result uses the first m slots of its planes
             dst = spec_dst;
             dst->npoints = m;
-            dst->mark_pending(c.stream);
             ranked = true;
         }
         spec_dst.reset();
