@@ -79,7 +79,7 @@ std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, 
     // from the host, so a caller that allows it gets the result back with that kernel still running.
     bool seen = false;
     if (ok && may_return_early && !profiling_enabled()) {
-        const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+        const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(poll_budget_us());
         for (int spin = 0;; spin++) {
             if ((uint32_t)(*word >> 32) == tag) { seen = true; break; }
             if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;

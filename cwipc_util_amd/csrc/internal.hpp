@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstddef>
 #include <memory>
 #include <utility>
@@ -95,6 +96,13 @@ struct ThreadCtx {
     ~ThreadCtx();
 };
 ThreadCtx &tctx();
+
+// How long a call polls pinned memory for a kernel's report before it falls back to an ordinary stream wait
+// (microseconds; CWIPC_POLL_US overrides, 0 = never poll: the test suite runs both ways).
+inline long poll_budget_us() {
+    const char *e = getenv("CWIPC_POLL_US");
+    return e ? atol(e) : 2000;
+}
 
 // Cached hipEvents without timing, for the `ready` marks of asynchronous results.
 hipEvent_t event_get();

@@ -2038,7 +2038,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             };
             bool seen = false;
             if (ok && !profiling_enabled()) {
-                const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+                const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(poll_budget_us());
                 for (int spin = 0;; spin++) {
                     if ((uint32_t)(words[C_COUNT] >> 32) == seq && take()) { seen = true; break; }
                     if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;

@@ -845,6 +845,24 @@ def test_input_freed_while_its_filter_result_is_pending(gpu, oracle, synth):
     assert not errors
 
 
+def test_without_polling(gpu, oracle, synth, monkeypatch):
+    """CWIPC_POLL_US=0: the calls that normally poll pinned memory for a kernel's report (downsample, tilefilter,
+    crop) fall back to the stream wait at once; same results."""
+    monkeypatch.setenv("CWIPC_POLL_US", "0")
+    pts, cs = synth(300000)
+    pc = make_cloud(gpu, pts, cs)
+    exp, _ = oracle.downsample(pts, cs, 0.01)
+    for _ in range(3):
+        got = gpu.cwipc_downsample(pc, 0.01).get_numpy_array()
+        assert len(got) == len(exp) and (got['tile'] == exp['tile']).all() and (got['r'] == exp['r']).all()
+        assert np.abs(got['x'] - exp['x']).max() <= XYZ_TOL
+        assert same(gpu.cwipc_tilefilter(pc, 1).get_numpy_array(), oracle.tilefilter(pts, 1))
+        assert same(gpu.cwipc_crop(pc, [-0.1, 0.1, 0.0, 1.0, -1, 1]).get_numpy_array(), oracle.crop(pts, [-0.1, 0.1, 0.0, 1.0, -1, 1]))
+    expg, _ = oracle.downsample(pts, cs, -0.01)
+    gotg = gpu.cwipc_downsample(pc, -0.01).get_numpy_array()
+    assert len(gotg) == len(expg) and (gotg['tile'] == expg['tile']).all()
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
