@@ -863,6 +863,56 @@ def test_without_polling(gpu, oracle, synth, monkeypatch):
     assert len(gotg) == len(expg) and (gotg['tile'] == expg['tile']).all()
 
 
+def test_synchronizer_with_the_device_join(gpu, oracle, synth):
+    """The tile synchroniser (cwipc_util_amd/net) on real clouds: its one n-ary GPU join against the reference's
+    left fold of pairwise joins (oracle/synchronizer.py), timestamps and cellsizes included."""
+    from cwipc_util_amd.net.source_synchronizer import SyncCore, cwipc_source_synchronizer
+    from oracle.synchronizer import ScriptedSource, run_reference_loop
+
+    class HostCloud:   # the oracle's side: numpy records
+        def __init__(self, pts, ts, cs): self.pts, self.ts, self.cs = pts, ts, cs
+        def timestamp(self): return self.ts
+        def cellsize(self): return self.cs
+        def payload(self): return self.pts
+
+    rng = np.random.default_rng(5)
+    base, _ = synth(20000)
+    scripts = []
+    for t in range(4):
+        ts, frames = 100 + t % 2, []
+        for f in range(5):
+            pts = base[rng.integers(0, len(base), int(rng.integers(1, 3000)))].copy()
+            pts['tile'] = 1 << t
+            frames.append((pts, ts, 0.001 * (1 + (t + f) % 3)))
+            ts += int(rng.integers(1, 3))
+        scripts.append(frames)
+    exp, exp_stats = run_reference_loop([ScriptedSource([HostCloud(*fr) for fr in frames]) for frames in scripts], oracle.join, True)
+    assert len(exp) >= 3
+
+    def device_sources():
+        return [ScriptedSource([make_cloud(gpu, p, cs, ts) for p, ts, cs in frames]) for frames in scripts]
+
+    core = SyncCore(device_sources())
+    got = []
+    while not any(s.eof() for s in core.sources):
+        r = core.poll()
+        if r is not None:
+            got.append(r)
+    assert len(got) == len(exp)
+    for g, (ts, cs, pts) in zip(got, exp):
+        assert g.timestamp() == ts and g.cellsize() == np.float32(cs)
+        assert same(g.get_numpy_array(), pts)
+    assert core.missing_per_occurrence == exp_stats["missing"] and core.late_per_occurrence == exp_stats["late"]
+    # the same through the thread and its queue
+    sync = cwipc_source_synchronizer(None, device_sources())
+    assert sync.start()
+    for ts, cs, pts in exp:
+        pc = sync.output_queue.get(timeout=60)
+        assert pc is not None and pc.timestamp() == ts and same(pc.get_numpy_array(), pts)
+    sync.stop()
+    assert sync.eof()
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
