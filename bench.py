@@ -116,6 +116,10 @@ def main() -> None:
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if world > 1 or os.environ.get("CWIPC_BENCH_FORCE_JOIN") == "1":
+        # the join's small kernels (pack, collective, unpack) run next to the next frame's downsample: leave them a few
+        # compute units (the library reads this when it is first used)
+        os.environ.setdefault("CWIPC_SPARE_CUS", "24")
     import torch
     import cwipc_util_amd as cwipc
 
@@ -128,9 +132,13 @@ def main() -> None:
     torch.cuda.set_device(device_index)
     cwipc.cwipc_hip_set_device(device_index)
     dist = None
-    if world > 1:
+    # CWIPC_BENCH_FORCE_JOIN=1: rehearsal of the N > 1 step (downsample + join over RCCL, pipelined) on ONE GPU,
+    # with a one-rank process group: everything of the multi-GPU path but the wire
+    force_join = world == 1 and os.environ.get("CWIPC_BENCH_FORCE_JOIN") == "1"
+    if world > 1 or force_join:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
@@ -154,9 +162,10 @@ def main() -> None:
     # N > 1: the join of frame i (a worker thread, as in the reference: net/source_synchronizer.py:17,184 joins on
     # a worker thread too) overlaps the downsample of frame i + 1; at most two frames are in flight, and every
     # frame's join has finished when the timed region ends.  CWIPC_BENCH_PIPELINE=0 runs them one after the other.
-    pipelined = world > 1 and os.environ.get("CWIPC_BENCH_PIPELINE", "1") != "0"
+    joining = world > 1 or force_join
+    pipelined = joining and os.environ.get("CWIPC_BENCH_PIPELINE", "1") != "0"
     joiner = None
-    if world > 1:
+    if joining:
         from cwipc_util_amd.multigpu import join_across_ranks
     if pipelined:
         import queue
@@ -197,7 +206,7 @@ def main() -> None:
         if joiner is not None:
             joiner.todo.put(out)
             return out
-        if world > 1:
+        if joining:
             out = join_across_ranks(out)
         return out
 
@@ -257,7 +266,7 @@ def main() -> None:
             "config": {
                 "workload": f"cwipc_synthetic({args.npoints}) -> cwipc_downsample(+{CELLSIZE}) [BASELINE configs[1]]"
                             + (f" per rank, tile masks 1<<rank, + all-gatherv join over {world} ranks"
-                               + (" (join of frame i overlaps the downsample of frame i+1)" if pipelined else "") if world > 1 else ""),
+                               + (" (join of frame i overlaps the downsample of frame i+1)" if pipelined else "") if joining else ""),
                 "points_per_gpu": n,
                 "bytes_per_gpu": 16 * n,
                 "outputs_per_gpu": n_out,

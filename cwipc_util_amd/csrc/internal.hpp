@@ -253,6 +253,8 @@ namespace k {
 
 // AoS (device) <-> SoA
 void aos_to_soa(const cwipc_point *aos, const DeviceSoA &dst, size_t n, hipStream_t s);
+constexpr int MAX_SLOTS = 64;
+void slots_to_soa(const void *slots, int nslots, size_t slot_rows, size_t header_rows, const uint32_t *counts, const DeviceSoA &dst, hipStream_t s);
 void soa_to_aos(const DeviceSoA &src, cwipc_point *aos, size_t n, hipStream_t s);
 
 // Stable compaction.  mode 0: tile == 0 || tile == pt.tile ; mode 1: half-open bbox ;

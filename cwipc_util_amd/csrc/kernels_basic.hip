@@ -48,11 +48,42 @@ __global__ void __launch_bounds__(BLOCK) soa_to_aos_kernel(const float *__restri
     }
 }
 
+// Gathered slots (one per rank, each with room for the largest cloud) -> planes, in slot order.
+struct SlotTable {
+    uint32_t first[MAX_SLOTS + 1];   // output index of slot s's first record; first[nslots] = total
+};
+__global__ void __launch_bounds__(BLOCK) slots_to_soa_kernel(const uint4 *__restrict__ slots, SlotTable t, int nslots, size_t slot_rows, size_t header_rows,
+                                                            float *__restrict__ x, float *__restrict__ y, float *__restrict__ z,
+                                                            uint32_t *__restrict__ rgbt) {
+    const size_t n = t.first[nslots];
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (; i < n; i += stride) {
+        int s = 0;
+        while (s + 1 < nslots && i >= t.first[s + 1]) s++;   // (a handful of slots: a scan beats a search)
+        const uint4 p = slots[(size_t)s * slot_rows + header_rows + (i - t.first[s])];
+        x[i] = __uint_as_float(p.x);
+        y[i] = __uint_as_float(p.y);
+        z[i] = __uint_as_float(p.z);
+        rgbt[i] = p.w;
+    }
+}
+
 static inline unsigned grid_for(size_t n, size_t per_block) {
     size_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
     if (g > 8192) g = 8192;   // grid-stride beyond 32 blocks per CU
     return (unsigned)g;
+}
+
+void slots_to_soa(const void *slots, int nslots, size_t slot_rows, size_t header_rows, const uint32_t *counts, const DeviceSoA &dst, hipStream_t s) {
+    SlotTable t;
+    uint32_t at = 0;
+    for (int i = 0; i < nslots; i++) { t.first[i] = at; at += counts[i]; }
+    for (int i = nslots; i <= MAX_SLOTS; i++) t.first[i] = at;
+    if (!at) return;
+    CW_LAUNCH("slots_to_soa", slots_to_soa_kernel, dim3(grid_for(at, BLOCK)), dim3(BLOCK), 0, s, (const uint4 *)slots, t, nslots, slot_rows, header_rows,
+              dst.x(), dst.y(), dst.z(), dst.rgbt());
 }
 
 void aos_to_soa(const cwipc_point *aos, const DeviceSoA &dst, size_t n, hipStream_t s) {

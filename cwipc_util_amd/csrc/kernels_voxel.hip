@@ -1870,7 +1870,11 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         ws.cus = cus_now;
         ws.cus_device = current_device();
     }
-    const int cus = ws.cus;
+    // CWIPC_SPARE_CUS=n leaves n compute units out of the persistent grid: a process that runs something else next
+    // to its downsamples (the multi-GPU join: pack, collective, unpack, all small) sets it, because K1's workgroups
+    // fill every CU they sit on and a kernel of another stream would otherwise wait for a whole K1 to finish.
+    static const int spare_cus = []() { const char *e = getenv("CWIPC_SPARE_CUS"); return e ? atoi(e) : 0; }();
+    const int cus = ws.cus - spare_cus > 8 ? ws.cus - spare_cus : ws.cus;
     // one persistent workgroup per CU; short clouds get fewer so that every wave has at least one step,
     // very large clouds get more (sequential) workgroups: the packed table needs < 65536 points per workgroup
     // Clouds with few points per voxel fill the workgroup table (2048 voxels): the previous calls of this

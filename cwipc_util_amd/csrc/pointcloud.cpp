@@ -671,6 +671,33 @@ extern "C" long cwipc_hip_copy_device_aos(cwipc_pointcloud *pc, void *dev_points
     return (long)dev->npoints;
 }
 
+extern "C" cwipc_pointcloud *cwipc_hip_from_device_slots(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
+                                                        const uint32_t *counts, uint64_t timestamp, float cellsize) {
+    if (!device_available("cwipc_hip_from_device_slots")) return nullptr;
+    if (nslots < 0 || nslots > k::MAX_SLOTS || (nslots > 0 && (dev_slots == nullptr || counts == nullptr))) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip_from_device_slots", "bad arguments (at most 64 slots)");
+        return nullptr;
+    }
+    size_t total = 0;
+    for (int i = 0; i < nslots; i++) {
+        if (header_rows + counts[i] > slot_rows) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip_from_device_slots", "a slot's count exceeds its rows");
+            return nullptr;
+        }
+        total += counts[i];
+    }
+    if (total >= ((size_t)1 << 32)) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto soa = soa_alloc(total);
+    if (!soa) return nullptr;
+    if (total) k::slots_to_soa(dev_slots, nslots, slot_rows, header_rows, counts, *soa, c.stream);
+    if (!c.sync()) return nullptr;   // the caller may reuse its receive buffer
+    auto *rv = new cwipc_hip_pointcloud();
+    rv->adopt_device(soa, timestamp, cellsize);
+    return rv;
+}
+
 extern "C" cwipc_pointcloud *cwipc_hip_from_device_aos(const void *dev_points, size_t npoint, uint64_t timestamp, float cellsize) {
     if (!device_available("cwipc_hip_from_device_aos")) return nullptr;
     ThreadCtx &c = tctx();

@@ -98,6 +98,9 @@ class SlotExchange:
         self.recv: Optional[torch.Tensor] = None
         self.collectives = 0   # for tests: how many collectives the last call needed
         self._overflow: Optional[torch.Tensor] = None
+        # the two header rows are written on the host; page-locked when they have to travel to a GPU
+        self._header = torch.zeros((self.HEADER_ROWS, 4), dtype=torch.int32, pin_memory=(device.type == "cuda"))
+        self._header_np = self._header.numpy()   # same memory: filled with one numpy assignment per frame
 
     def _resize(self, need: int) -> None:
         cap = ((int(need * 1.25) + 4095) // 4096) * 4096
@@ -105,6 +108,8 @@ class SlotExchange:
         rows = self.cap + self.HEADER_ROWS
         self.send = torch.zeros((rows, 4), dtype=torch.int32, device=self.device)
         self.recv = torch.zeros((self.world, rows, 4), dtype=torch.int32, device=self.device)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream().synchronize()   # the library's streams write into / read from these buffers
 
     def _agree_on_capacity(self, n_local: int) -> None:
         mine = torch.tensor([n_local], dtype=torch.int64, device=self.device)
@@ -125,6 +130,16 @@ class SlotExchange:
     def gather(self, n_local: int, timestamp: int, cellsize: float, has_cloud: bool = True) -> Tuple[torch.Tensor, int, float, List[int]]:
         """After the points are in slot_points(n_local): returns (fused int32[n_total, 4], min timestamp, min cellsize, counts).
         Collective: every rank of the group calls it, once per frame."""
+        ts_min, cs_min, counts = self.gather_slots(n_local, timestamp, cellsize, has_cloud)
+        if sum(counts) == 0:
+            return torch.empty((0, 4), dtype=torch.int32, device=self.device), ts_min, cs_min, counts
+        fused = torch.cat([self.recv[r, self.HEADER_ROWS:self.HEADER_ROWS + counts[r]] for r in range(self.world) if counts[r]], dim=0)
+        return fused, ts_min, cs_min, counts
+
+    def gather_slots(self, n_local: int, timestamp: int, cellsize: float, has_cloud: bool = True) -> Tuple[int, float, List[int]]:
+        """The collective itself: afterwards self.recv[r, HEADER_ROWS : HEADER_ROWS + counts[r]] holds rank r's points.
+        Returns (min timestamp, min cellsize, counts); the library turns the slots into a cloud in one pass
+        (cwipc_hip_from_device_slots), gather() concatenates them into a tensor."""
         import struct
         self.collectives = 0
         if self.cap == 0:
@@ -133,17 +148,18 @@ class SlotExchange:
         ts = int(timestamp) & 0xffffffffffffffff
         as_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
         cs_bits = struct.unpack("<i", struct.pack("<f", float(cellsize)))[0]
-        header = torch.tensor([[n_local, 1 if has_cloud else 0, cs_bits, 0], [as_i32(ts & 0xffffffff), as_i32(ts >> 32), 0, 0]], dtype=torch.int32)
+        header = self._header
+        self._header_np[:] = ((n_local, 1 if has_cloud else 0, cs_bits, 0), (as_i32(ts & 0xffffffff), as_i32(ts >> 32), 0, 0))
         while True:
-            self.send[:self.HEADER_ROWS].copy_(header)
+            self.send[:self.HEADER_ROWS].copy_(header, non_blocking=True)   # (the read-back of the headers below waits for it)
             rows = self.cap + self.HEADER_ROWS
             if self.device.type == "cuda":
                 dist.all_gather_into_tensor(self.recv.view(self.world * rows, 4), self.send, group=self.group)
             else:   # gloo: list form, same bytes
                 dist.all_gather([self.recv[r] for r in range(self.world)], self.send, group=self.group)
             self.collectives += 1
-            heads = self.recv[:, :self.HEADER_ROWS, :].cpu()
-            counts = [int(v) for v in heads[:, 0, 0].tolist()]
+            heads = self.recv[:, :self.HEADER_ROWS, :].cpu().numpy()   # (world, 2, 4) int32; waits for the collective
+            counts = [int(v) for v in heads[:, 0, 0]]
             if max(counts) <= self.cap:
                 break
             # somebody's cloud outgrew the slots (its points were not sent): every rank sees that in the
@@ -153,19 +169,14 @@ class SlotExchange:
             if keep is not None:
                 self.send[self.HEADER_ROWS:self.HEADER_ROWS + n_local] = keep
             self._adopt_overflow(n_local)
-        part = heads[:, 0, 1] > 0
-        if bool(part.any()):
-            lo = heads[:, 1, 0].to(torch.int64) & 0xffffffff
-            hi = heads[:, 1, 1].to(torch.int64) & 0xffffffff
-            stamps = (hi << 32) | lo   # below 2^63 for any real timestamp
-            ts_min = int(stamps[part].min().item())
-            cs_min = float(heads[:, 0, 2][part].contiguous().view(torch.float32).min().item())
-        else:
-            ts_min, cs_min = 0, 0.0
-        if sum(counts) == 0:
-            return torch.empty((0, 4), dtype=torch.int32, device=self.device), ts_min, cs_min, counts
-        fused = torch.cat([self.recv[r, self.HEADER_ROWS:self.HEADER_ROWS + counts[r]] for r in range(self.world) if counts[r]], dim=0)
-        return fused, ts_min, cs_min, counts
+        # min timestamp and min cellsize over the ranks that had a cloud (plain Python on 2 x world numbers)
+        stamps, sizes = [], []
+        for r in range(self.world):
+            if heads[r, 0, 1] > 0:
+                stamps.append(((int(heads[r, 1, 1]) & 0xffffffff) << 32) | (int(heads[r, 1, 0]) & 0xffffffff))
+                sizes.append(struct.unpack("<f", struct.pack("<i", int(heads[r, 0, 2])))[0])
+        ts_min, cs_min = (min(stamps), min(sizes)) if stamps else (0, 0.0)
+        return ts_min, cs_min, counts
 
     def _adopt_overflow(self, n_local: int) -> None:
         if self._overflow is not None and n_local <= self.cap:
@@ -198,10 +209,13 @@ def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
             util.cwipc_hip_copy_device_aos(pc, tmp.data_ptr(), n * 16)
             slot.copy_(tmp)
         else:
-            torch.cuda.current_stream().synchronize()          # the slot tensor is ready for another stream's kernel
+            # (the slot is free: torch's last use of it, the previous frame's collective, was waited for when that
+            # frame's headers were read back; a new buffer is waited for where it is made)
             util.cwipc_hip_copy_device_aos(pc, slot.data_ptr(), n * 16)   # returns after the library's stream has finished
-    fused, ts, cs, _counts = ex.gather(n, ts, cs, has)
+    ts, cs, counts = ex.gather_slots(n, ts, cs, has)
+    recv = ex.recv.to(dev) if staged else ex.recv   # (world, cap + HEADER_ROWS, 4) int32
     if staged:
-        fused = fused.to(dev)
-    torch.cuda.current_stream().synchronize()
-    return util.cwipc_hip_from_device_aos(fused.data_ptr() if fused.shape[0] else 0, fused.shape[0], ts, cs)
+        torch.cuda.current_stream().synchronize()
+    # (device path: reading the headers back has already waited for the collective that filled recv)
+    # slots -> planes of the fused cloud in one pass of the library (no concatenated copy in between)
+    return util.cwipc_hip_from_device_slots(recv.data_ptr(), recv.shape[1], ex.HEADER_ROWS, counts, ts, cs)

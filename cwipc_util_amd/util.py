@@ -40,7 +40,7 @@ __all__ = [
     'cwipc_join', 'cwipc_join_multi', 'cwipc_crop',
     # MI355X extensions (no reference counterpart)
     'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked',
-    'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_copy_device_aos',
+    'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_from_device_slots', 'cwipc_hip_copy_device_aos',
     'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used',
 ]
 
@@ -203,6 +203,7 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
                                  _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)], _c.c_int),
     'cwipc_hip_copy_device_aos': ([cwipc_pointcloud_p, _c.c_void_p, _c.c_size_t], _c.c_long),
     'cwipc_hip_from_device_aos': ([_c.c_void_p, _c.c_size_t, _c.c_uint64, _c.c_float], cwipc_pointcloud_p),
+    'cwipc_hip_from_device_slots': ([_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_size_t, _c.POINTER(_c.c_uint32), _c.c_uint64, _c.c_float], cwipc_pointcloud_p),
     'cwipc_hip_colorize': ([cwipc_pointcloud_p, _c.c_double, _c.c_void_p, _c.c_void_p], cwipc_pointcloud_p),
     'cwipc_hip_join_multi': ([_c.POINTER(cwipc_pointcloud_p), _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_tilefilter_masked': ([cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
@@ -871,6 +872,14 @@ def cwipc_hip_from_device_aos(dev_ptr: int, npoint: int, timestamp: int, cellsiz
     """New cloud from npoint cwipc_point records at a DEVICE address (e.g. torch tensor .data_ptr())."""
     rv = cwipc_util_dll_load().cwipc_hip_from_device_aos(dev_ptr, npoint, timestamp, cellsize)
     return _wrap_filter_result('cwipc_hip_from_device_aos', rv)
+
+
+def cwipc_hip_from_device_slots(dev_ptr: int, slot_rows: int, header_rows: int, counts: List[int], timestamp: int, cellsize: float) -> cwipc_pointcloud_wrapper:
+    """New cloud from the receive buffer of an all-gather at a DEVICE address: len(counts) slots of slot_rows
+    16-byte rows, the records of slot s in rows [header_rows, header_rows + counts[s]); slot order = point order."""
+    arr = (ctypes.c_uint32 * len(counts))(*counts)
+    rv = cwipc_util_dll_load().cwipc_hip_from_device_slots(dev_ptr, len(counts), slot_rows, header_rows, arr, timestamp, cellsize)
+    return _wrap_filter_result('cwipc_hip_from_device_slots', rv)
 
 
 def cwipc_hip_copy_device_aos(pc: cwipc_pointcloud_wrapper, dev_ptr: int, size: int) -> int:

@@ -39,6 +39,11 @@ _CWIPC_UTIL_EXPORT int cwipc_hip_device_planes(cwipc_pointcloud *pc, const float
 _CWIPC_UTIL_EXPORT long cwipc_hip_copy_device_aos(cwipc_pointcloud *pc, void *dev_points, size_t size);
 /* New cloud from cwipc_point records that already are in device memory. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_aos(const void *dev_points, size_t npoint, uint64_t timestamp, float cellsize);
+/* The same from the receive buffer of an all-gather (the multi-GPU join, reference cwipc_join folded over the tiles,
+   src/cwipc_filters.cpp:388-418): nslots (<= 64) slots of slot_rows 16-byte rows each in device memory, the records of
+   slot s in rows [header_rows, header_rows + counts[s]); the new cloud holds them in slot order.  counts is a host array. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_slots(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
+                                                                 const uint32_t *counts, uint64_t timestamp, float cellsize);
 
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */

@@ -913,6 +913,32 @@ def test_synchronizer_with_the_device_join(gpu, oracle, synth):
     assert sync.eof()
 
 
+def test_from_device_slots(gpu, oracle, synth):
+    """The receive buffer of the multi-GPU join (one slot per rank: header rows, then that rank's records) becomes
+    the fused cloud in one pass; same bytes as joining the per-rank clouds one after the other."""
+    import torch
+    pts, _ = synth(50000)
+    parts = [pts[:0], pts[:7], pts[100:100 + 4096], pts[5000:5001], pts[10000:10000 + 12345]]
+    rows, header = 12345 + 2 + 13, 2
+    buf = np.zeros((len(parts), rows, 4), dtype=np.int32)
+    buf[:, :, :] = -7                                   # rows outside [header, header + count) must not matter
+    for s, part in enumerate(parts):
+        buf[s, header:header + len(part)] = part.view(np.int32).reshape(-1, 4)
+    dev = torch.from_numpy(buf).to("cuda")
+    torch.cuda.synchronize()
+    out = gpu.cwipc_hip_from_device_slots(dev.data_ptr(), rows, header, [len(p) for p in parts], 4242, 0.25)
+    exp = parts[0]
+    for part in parts[1:]:
+        exp = oracle.join(exp, part)
+    assert out.timestamp() == 4242 and out.cellsize() == 0.25
+    assert same(out.get_numpy_array(), exp)
+    # nothing at all
+    assert gpu.cwipc_hip_from_device_slots(dev.data_ptr(), rows, header, [0, 0], 1, 1.0).count() == 0
+    # a count that does not fit its slot is refused
+    with pytest.raises(gpu.CwipcError):
+        gpu.cwipc_hip_from_device_slots(dev.data_ptr(), rows, header, [rows], 1, 1.0)
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
