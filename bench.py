@@ -13,7 +13,11 @@ N > 1 (weak scaling): every rank holds one camera tile of the same size (tile ma
 runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join
 (cwipc_util_amd.multigpu) -- the path's one exchange step.  Frames stream: the join of frame i runs on a
 worker thread while the main thread downsamples frame i + 1 (at most two frames in flight; all joins are
-complete when the timed region ends).
+complete when the timed region ends).  For N > 1 the library is told to leave 24 compute units out of the
+voxel kernel's persistent grid (CWIPC_SPARE_CUS, unless already set), so that the join's small kernels do not
+wait for a whole downsample.  Rehearsal knobs: CWIPC_BENCH_BACKEND=gloo (several ranks on one GPU, exchange
+staged through the host), CWIPC_BENCH_FORCE_JOIN=1 (N = 1 with a one-rank RCCL group: the whole N > 1 step
+but the wire), CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other).
 
 One JSON line on rank 0.  `value` = points filtered by all ranks / wall time of the K timed steps
 (max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel
