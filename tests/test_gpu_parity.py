@@ -939,6 +939,30 @@ def test_from_device_slots(gpu, oracle, synth):
         gpu.cwipc_hip_from_device_slots(dev.data_ptr(), rows, header, [rows], 1, 1.0)
 
 
+def test_path_vectors(gpu):
+    """The HIP path against the committed vectors (tests/golden/path_vectors.npz), without the oracle in the loop."""
+    d = np.load(os.path.join(GOLDEN, "path_vectors.npz"))
+    pts, cs = d["input"], float(d["cellsize"])
+    pc = make_cloud(gpu, pts, cs, 99)
+    for name, cell in (("down_p05", 0.05), ("down_p20", 0.2), ("down_m05", -0.05), ("down_m20", -0.2)):
+        out = gpu.cwipc_downsample(pc, cell)
+        got, exp = out.get_numpy_array(), d[name]
+        assert len(got) == len(exp) and np.float32(out.cellsize()) == d[name + "_cellsize"]
+        for f in ('r', 'g', 'b', 'tile'):
+            assert (got[f] == exp[f]).all()
+        for f in ('x', 'y', 'z'):
+            assert np.abs(got[f] - exp[f]).max() <= XYZ_TOL
+    md, _ = gpu.cwipc_hip_knn_mean_dist(pc, 8, 1.0)
+    assert md.tobytes() == d["knn8"].tobytes()
+    assert same(gpu.cwipc_remove_outliers(pc, 8, 1.0, False).get_numpy_array(), d["sor_k8_s1"])
+    assert same(gpu.cwipc_remove_outliers(pc, 8, 1.0, True).get_numpy_array(), d["sor_k8_s1_pertile"])
+    assert same(gpu.cwipc_tilefilter(pc, 1).get_numpy_array(), d["tilefilter_1"])
+    assert same(gpu.cwipc_crop(pc, [-0.1, 0.2, 0.5, 1.5, -0.3, 0.05]).get_numpy_array(), d["crop"])
+    assert same(gpu.cwipc_colormap(pc, 0x00ff00ff, 0x05000007).get_numpy_array(), d["colormap"])
+    assert same(gpu.cwipc_tilemap(pc, bytes((i * 7 + 3) % 256 for i in range(256))).get_numpy_array(), d["tilemap"])
+    assert same(gpu.cwipc_join(make_cloud(gpu, pts[:100], cs), make_cloud(gpu, pts[300:], cs)).get_numpy_array(), d["join"])
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc

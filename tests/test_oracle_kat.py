@@ -200,3 +200,22 @@ def test_knn_against_bruteforce(oracle):
         nearest = np.sort(d2)[1:k + 1]
         expect = np.float32(np.sqrt(nearest, dtype=np.float32).astype(np.float64).sum() / k)
         assert got[i] == expect
+
+
+def test_path_vectors_are_reproduced(oracle):
+    """tests/golden/path_vectors.npz (made by tests/golden/make_path_vectors.py from this oracle): the restatement
+    still says what it said when the vectors were committed -- a guard against drift of the checker itself."""
+    d = np.load(os.path.join(GOLDEN, "path_vectors.npz"))
+    pts, cs = d["input"], float(d["cellsize"])
+    same = lambda a, b: len(a) == len(b) and a.tobytes() == b.tobytes()
+    for name, cell in (("down_p05", 0.05), ("down_p20", 0.2), ("down_m05", -0.05), ("down_m20", -0.2)):
+        res, out_cs = oracle.downsample(pts, cs, cell)
+        assert same(res, d[name]) and np.float32(out_cs) == d[name + "_cellsize"]
+    assert oracle.knn_mean_dist(pts, 8).tobytes() == d["knn8"].tobytes()
+    assert same(oracle.remove_outliers(pts, 8, 1.0, False), d["sor_k8_s1"])
+    assert same(oracle.remove_outliers(pts, 8, 1.0, True), d["sor_k8_s1_pertile"])
+    assert same(oracle.tilefilter(pts, 1), d["tilefilter_1"])
+    assert same(oracle.crop(pts, [-0.1, 0.2, 0.5, 1.5, -0.3, 0.05]), d["crop"])
+    assert same(oracle.colormap(pts, 0x00ff00ff, 0x05000007), d["colormap"])
+    assert same(oracle.tilemap(pts, bytes((i * 7 + 3) % 256 for i in range(256))), d["tilemap"])
+    assert same(oracle.join(pts[:100], pts[300:]), d["join"])
