@@ -753,7 +753,9 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             uint32_t *tab = L.nn_leaf[threadIdx.x >> 6];
             uint32_t s0 = tab[o0.nn], s1 = tab[o1.nn], s2 = tab[o2.nn], s3 = tab[o3.nn];
             const auto unknown = [](const PointOut &o, uint32_t sl) { return o.key != KEY_EMPTY && sl == 0xffffffffu; };
-            if (__builtin_expect(__ballot(unknown(o0, s0) || unknown(o1, s1) || unknown(o2, s2) || unknown(o3, s3)) != 0ull, 0)) {
+            // (first a test that may raise a false alarm for points that do not count: one maximum instead of
+            // four two-part conditions; the loop behind it looks closely)
+            if (__builtin_expect(__ballot(max(max(s0, s1), max(s2, s3)) == 0xffffffffu) != 0ull, 0)) {
                 for (;;) {
                     const uint32_t want = unknown(o0, s0) ? o0.nn : unknown(o1, s1) ? o1.nn : unknown(o2, s2) ? o2.nn : unknown(o3, s3) ? o3.nn : 0xffu;
                     const unsigned long long need = __ballot(want != 0xffu);
