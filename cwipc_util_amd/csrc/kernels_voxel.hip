@@ -1098,9 +1098,12 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
                                                             uint32_t *__restrict__ ctrl, const unsigned long long *__restrict__ leaf_keys,
                                                             uint32_t leaf_cap, uint32_t *__restrict__ next_head, uint32_t next_head_words,
                                                             uint32_t *__restrict__ host_out, uint32_t seq) {
-    // housekeeping this single workgroup has threads to spare for: zero the control block the NEXT call
-    // will use (the two blocks alternate, so no memset sits in front of the next call's first kernel)
-    for (uint32_t i = threadIdx.x; i < next_head_words; i += 1024) next_head[i] = 0u;
+    // housekeeping this single workgroup has threads to spare for: it zeroes the control block the NEXT call
+    // on this workspace will use (the two blocks alternate, so no memset sits in front of that call's first
+    // kernel) -- at the very end, after the results have gone out to the host, which is waiting for them
+    const auto zero_next_head = [&]() {
+        for (uint32_t i = threadIdx.x; i < next_head_words; i += 1024) next_head[i] = 0u;
+    };
     __shared__ double s_mn[3], s_mx[3];
     __shared__ int s_resolved;
     __shared__ int s_depth;
@@ -1148,6 +1151,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         __syncthreads();
         // results straight into the host's pinned words: the host only waits for the stream
         publish(ctrl, host_out, seq);
+        zero_next_head();
         return;
     }
 
@@ -1317,6 +1321,7 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
     }
     __syncthreads();
     publish(ctrl, host_out, seq);
+    zero_next_head();
 }
 
 // ---------------------------------------------------------------------------
