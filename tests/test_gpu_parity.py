@@ -963,6 +963,29 @@ def test_path_vectors(gpu):
     assert same(gpu.cwipc_join(make_cloud(gpu, pts[:100], cs), make_cloud(gpu, pts[300:], cs)).get_numpy_array(), d["join"])
 
 
+def test_hundred_million_points(gpu, oracle, synth):
+    """1.6 GB of points: more workgroups than compute units in the voxel kernel, index arithmetic well beyond 2^24,
+    a tilefilter result of 800 MB.  Against the oracle (which needs a few seconds here)."""
+    pts, cs = synth(100_000_000)
+    assert len(pts) > 99_000_000
+    pc = make_cloud(gpu, pts, cs)
+    gpu.cwipc_hip_upload(pc, drop_host_copy=True)
+    for cell in (0.01, -0.01):
+        got = gpu.cwipc_downsample(pc, cell).get_numpy_array()
+        exp, _ = oracle.downsample(pts, cs, cell)
+        assert len(got) == len(exp)
+        for f in ('r', 'g', 'b', 'tile'):
+            assert (got[f] == exp[f]).all()
+        # ~2500 points per voxel (and whole rows at the apex): the oracle's fp32 running sums, PCL's AccumulatorXYZ,
+        # reach thousands, where one ulp is 5e-4 -- the bar here is the checker's own rounding, not the HIP path's
+        # (which sums integers and rounds once: test_downsample_means_are_correctly_rounded)
+        for f in ('x', 'y', 'z'):
+            assert np.abs(got[f].astype(np.float64) - exp[f]).max() <= 2e-3
+    got = gpu.cwipc_tilefilter(pc, 1).get_numpy_array()
+    exp = oracle.tilefilter(pts, 1)
+    assert len(got) == len(exp) and got.tobytes() == exp.tobytes()
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
