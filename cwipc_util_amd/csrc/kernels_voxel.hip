@@ -1583,8 +1583,31 @@ __device__ __forceinline__ uint32_t voxelgrid_index(const VoxParams &P, const Vo
     return (uint32_t)(d[0] + d[1] * dx + d[2] * dx * dy);
 }
 
+// The five passes below can be launched before the host knows the outcome of the pass (right behind the replay
+// kernel, like rank_emit_kernel on the octree path): they then take count and grid size from the control block
+// and do nothing at all unless the pass succeeded and everything fits what the host provided for.
+struct GridSpec {
+    int on;                        // 0: m and nwords are the host's
+    uint32_t m_cap;                // room in the result
+    uint32_t words_cap;            // room in the index bitmap
+    unsigned long long cells_max;  // largest index space the bitmap path takes
+};
+struct GridGate { uint32_t m, nwords; bool go; };
+__device__ __forceinline__ GridGate grid_gate(const VoxWork &W, uint32_t m_host, uint32_t nwords_host, const GridSpec &spec) {
+    if (!spec.on) return GridGate{m_host, nwords_host, true};
+    const uint32_t m = W.ctrl[C_COUNT], err = W.ctrl[C_ERR];
+    const unsigned long long cells = (unsigned long long)W.ctrl[C_DIVB] * W.ctrl[C_DIVB + 1] * W.ctrl[C_DIVB + 2];
+    const unsigned long long nwords = (cells + 31) / 32;
+    const bool go = err == 0u && m != 0u && m <= spec.m_cap && cells <= spec.cells_max && nwords <= spec.words_cap;
+    return GridGate{m, (uint32_t)nwords, go};
+}
+
 // one bit per touched record; its index is kept for the passes that follow
-__global__ void __launch_bounds__(256) grid_mark_kernel(VoxParams P, VoxWork W, uint32_t m, uint32_t *__restrict__ gbits, uint32_t *__restrict__ gidx) {
+__global__ void __launch_bounds__(256) grid_mark_kernel(VoxParams P, VoxWork W, uint32_t m_host, GridSpec spec, uint32_t *__restrict__ gbits,
+                                                       uint32_t *__restrict__ gidx) {
+    const GridGate gate = grid_gate(W, m_host, 0u, spec);
+    if (!gate.go) return;
+    const uint32_t m = gate.m;
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
     const uint32_t idx = voxelgrid_index(P, W, W.occupied[r]);
@@ -1593,9 +1616,13 @@ __global__ void __launch_bounds__(256) grid_mark_kernel(VoxParams P, VoxWork W, 
 }
 
 // per block of 1024 bitmap words: set bits before each word (inside the block), set bits of the block
-__global__ void __launch_bounds__(256) grid_block_kernel(const uint32_t *__restrict__ gbits, uint32_t nwords, uint32_t *__restrict__ word_prefix,
-                                                        uint32_t *__restrict__ block_sum) {
+__global__ void __launch_bounds__(256) grid_block_kernel(VoxWork W, GridSpec spec, const uint32_t *__restrict__ gbits, uint32_t nwords_host,
+                                                        uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ block_sum) {
     __shared__ uint32_t wave_tot[4];
+    const GridGate gate = grid_gate(W, 0u, nwords_host, spec);
+    if (!gate.go) return;
+    const uint32_t nwords = gate.nwords;
+    if (blockIdx.x * (uint32_t)GB_WORDS_PER_BLOCK >= nwords) return;   // (a speculative launch covers the whole bitmap buffer)
     const uint32_t w0 = blockIdx.x * GB_WORDS_PER_BLOCK + threadIdx.x * 4;
     uint32_t c[4];
     uint32_t mine = 0;
@@ -1626,9 +1653,12 @@ __global__ void __launch_bounds__(256) grid_block_kernel(const uint32_t *__restr
 }
 
 // exclusive scan of the block sums, one workgroup
-__global__ void __launch_bounds__(1024) grid_blockscan_kernel(uint32_t *__restrict__ block_sum, uint32_t nblocks) {
+__global__ void __launch_bounds__(1024) grid_blockscan_kernel(VoxWork W, GridSpec spec, uint32_t *__restrict__ block_sum, uint32_t nwords_host) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
+    const GridGate gate = grid_gate(W, 0u, nwords_host, spec);
+    if (!gate.go) return;
+    const uint32_t nblocks = (gate.nwords + GB_WORDS_PER_BLOCK - 1) / GB_WORDS_PER_BLOCK;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1653,10 +1683,13 @@ __global__ void __launch_bounds__(1024) grid_blockscan_kernel(uint32_t *__restri
 }
 
 // rank of the record's bit = its output position; emit, clean the record and the leaf bitmap bit
-__global__ void __launch_bounds__(256) grid_emit_kernel(VoxParams P, VoxWork W, uint32_t m, const uint32_t *__restrict__ gidx,
+__global__ void __launch_bounds__(256) grid_emit_kernel(VoxParams P, VoxWork W, uint32_t m_host, GridSpec spec, const uint32_t *__restrict__ gidx,
                                                        const uint32_t *__restrict__ gbits, const uint32_t *__restrict__ word_prefix,
                                                        const uint32_t *__restrict__ block_sum, float *__restrict__ ox, float *__restrict__ oy,
                                                        float *__restrict__ oz, uint32_t *__restrict__ ow) {
+    const GridGate gate = grid_gate(W, m_host, 0u, spec);
+    if (!gate.go) return;
+    const uint32_t m = gate.m;
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
     const uint32_t key = W.occupied[r], idx = gidx[r], w = idx >> 5;
@@ -1667,9 +1700,12 @@ __global__ void __launch_bounds__(256) grid_emit_kernel(VoxParams P, VoxWork W, 
 }
 
 // the index bitmap is left zeroed for the next call (after every rank has been read)
-__global__ void __launch_bounds__(256) grid_unmark_kernel(uint32_t m, const uint32_t *__restrict__ gidx, uint32_t *__restrict__ gbits) {
+__global__ void __launch_bounds__(256) grid_unmark_kernel(VoxWork W, uint32_t m_host, GridSpec spec, const uint32_t *__restrict__ gidx,
+                                                         uint32_t *__restrict__ gbits) {
+    const GridGate gate = grid_gate(W, m_host, 0u, spec);
+    if (!gate.go) return;
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r < m) gbits[gidx[r] >> 5] = 0u;
+    if (r < gate.m) gbits[gidx[r] >> 5] = 0u;
 }
 
 // Error path of the octree variant (no list of touched records there): zero every record whose bit is
@@ -1707,6 +1743,7 @@ struct Workspace {
     int parity = 0;                    // block of the next pass
     uint32_t seq = 0;                  // sequence number of the last pass (never 0 once used)
     uint32_t last_m = 0;               // outputs of this thread's last octree pass (sizes the speculative result of the next)
+    uint32_t last_m_grid = 0;          //   ... and of its last plain-grid pass
     int shrink = 0;                    // log2 of how much smaller than "one workgroup per CU" the workgroups are made (sparse clouds)
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
     bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
@@ -2034,6 +2071,28 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 spec_dst->mark_pending(c.stream);
             }
         }
+        // Plain grid: the same, five small kernels instead of one (mark, block counts, block scan, emit, unmark), with
+        // room for last call's count (+25 %) and the index bitmap as it stands; each of them checks on the device
+        // that the pass succeeded and fits, and does nothing otherwise.
+        GridSpec gspec{0, 0u, 0u, 0ull};
+        unsigned long long bitmap_max = GRID_BITMAP_MAX_CELLS;
+        if (const char *e = getenv("CWIPC_GRID_BITMAP_MAX")) bitmap_max = strtoull(e, nullptr, 10);   // test knob: force the sort path
+        if (ok && !leaf_split && ws.last_m_grid > 0 && ws.gwords_cap > 0 && !profiling_enabled()) {
+            spec_cap = ws.last_m_grid + ws.last_m_grid / 4 + 1024;
+            if (spec_cap > P.list_cap) spec_cap = P.list_cap;
+            spec_dst = soa_alloc(spec_cap);
+            if (spec_dst) {
+                gspec = GridSpec{1, spec_cap, (uint32_t)std::min<size_t>(ws.gwords_cap, 0xffffffffu), bitmap_max};
+                const unsigned sgrid = (spec_cap + 255) / 256, sblk = (unsigned)((gspec.words_cap + GB_WORDS_PER_BLOCK - 1) / GB_WORDS_PER_BLOCK);
+                hipLaunchKernelGGL(grid_mark_kernel, dim3(sgrid), dim3(256), 0, c.stream, P, W, 0u, gspec, ws.gbits, ws.order);
+                hipLaunchKernelGGL(grid_block_kernel, dim3(sblk), dim3(256), 0, c.stream, W, gspec, ws.gbits, 0u, ws.gprefix, ws.gblock);
+                hipLaunchKernelGGL(grid_blockscan_kernel, dim3(1), dim3(1024), 0, c.stream, W, gspec, ws.gblock, 0u);
+                hipLaunchKernelGGL(grid_emit_kernel, dim3(sgrid), dim3(256), 0, c.stream, P, W, 0u, gspec, ws.order, ws.gbits, ws.gprefix, ws.gblock,
+                                   spec_dst->x(), spec_dst->y(), spec_dst->z(), spec_dst->rgbt());
+                hipLaunchKernelGGL(grid_unmark_kernel, dim3(sgrid), dim3(256), 0, c.stream, W, 0u, gspec, ws.order, ws.gbits);
+                spec_dst->mark_pending(c.stream);
+            }
+        }
         // wait for the replay kernel's sequence number in pinned memory (a few hundred microseconds of
         // polling at most, then the ordinary stream wait, which also reports launch failures)
         uint32_t hw[C_SEQ];   // the published control words
@@ -2091,7 +2150,18 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         const unsigned mgrid = (m + 255) / 256;
 
         bool ranked = false;
+        bool grid_ranked = false;
         if (leaf_split) ws.last_m = err ? 0 : m;
+        else ws.last_m_grid = err ? 0 : m;
+        if (!err && m && !leaf_split && spec_dst && gspec.on) {
+            // did the speculative passes run?  (the test they made on the device, on the same words)
+            const unsigned long long cells = (unsigned long long)hw[C_DIVB] * hw[C_DIVB + 1] * hw[C_DIVB + 2];
+            if (hw[C_COUNT] <= gspec.m_cap && cells <= gspec.cells_max && (cells + 31) / 32 <= gspec.words_cap) {
+                dst = spec_dst;
+                dst->npoints = m;
+                grid_ranked = true;
+            }
+        }
         if (!err && m && leaf_split && spec_dst && m <= spec_cap) {
             // the speculative finalize pass is doing the work: the result uses the first m slots of its planes
             dst = spec_dst;
@@ -2114,13 +2184,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 ranked = true;
             }
         }
-        bool grid_ranked = false;
-        if (!err && m && !leaf_split) {
+        if (!err && m && !leaf_split && !grid_ranked) {
             // plain grid, the usual case: output order from a bitmap over the VoxelGrid index space, no sort;
             // like the octree variant the call returns with these passes in flight
             const unsigned long long cells = (unsigned long long)hw[C_DIVB] * hw[C_DIVB + 1] * hw[C_DIVB + 2];
-            unsigned long long bitmap_max = GRID_BITMAP_MAX_CELLS;
-            if (const char *e = getenv("CWIPC_GRID_BITMAP_MAX")) bitmap_max = strtoull(e, nullptr, 10);   // test knob: force the sort path
             if (cells <= bitmap_max) {
                 const uint32_t nwords = (uint32_t)((cells + 31) / 32), nblk = (nwords + GB_WORDS_PER_BLOCK - 1) / GB_WORDS_PER_BLOCK;
                 bool ready = true;
@@ -2137,12 +2204,13 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 }
                 dst = ready ? soa_alloc(m) : nullptr;
                 if (dst) {
-                    CW_LAUNCH("grid_mark", grid_mark_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, ws.gbits, ws.order);
-                    CW_LAUNCH("grid_block", grid_block_kernel, dim3(nblk), dim3(256), 0, c.stream, ws.gbits, nwords, ws.gprefix, ws.gblock);
-                    CW_LAUNCH("grid_blockscan", grid_blockscan_kernel, dim3(1), dim3(1024), 0, c.stream, ws.gblock, nblk);
-                    CW_LAUNCH("grid_emit", grid_emit_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, ws.order, ws.gbits, ws.gprefix, ws.gblock,
+                    const GridSpec known{0, 0u, 0u, 0ull};
+                    CW_LAUNCH("grid_mark", grid_mark_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, known, ws.gbits, ws.order);
+                    CW_LAUNCH("grid_block", grid_block_kernel, dim3(nblk), dim3(256), 0, c.stream, W, known, ws.gbits, nwords, ws.gprefix, ws.gblock);
+                    CW_LAUNCH("grid_blockscan", grid_blockscan_kernel, dim3(1), dim3(1024), 0, c.stream, W, known, ws.gblock, nwords);
+                    CW_LAUNCH("grid_emit", grid_emit_kernel, dim3(mgrid), dim3(256), 0, c.stream, P, W, m, known, ws.order, ws.gbits, ws.gprefix, ws.gblock,
                               dst->x(), dst->y(), dst->z(), dst->rgbt());
-                    CW_LAUNCH("grid_unmark", grid_unmark_kernel, dim3(mgrid), dim3(256), 0, c.stream, m, ws.order, ws.gbits);
+                    CW_LAUNCH("grid_unmark", grid_unmark_kernel, dim3(mgrid), dim3(256), 0, c.stream, W, m, known, ws.order, ws.gbits);
                     dst->mark_pending(c.stream);
                     grid_ranked = true;
                 }
