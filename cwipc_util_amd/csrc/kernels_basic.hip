@@ -488,9 +488,12 @@ void tiles_used(const DeviceSoA &src, uint32_t *dev_bits8, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // join: plane-wise concatenation
 // ---------------------------------------------------------------------------
+// blockIdx.y selects the plane.  Planes start on 1 KiB boundaries, so a part whose destination offset is a multiple
+// of four points (the usual case: clouds of any size first, and every count that is a multiple of 4 after) can
+// move 16 bytes per lane; the general form moves 4.
+template <bool VEC>
 __global__ void __launch_bounds__(BLOCK) join_copy_kernel(JoinPart part, float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
                                                          uint32_t *__restrict__ ow) {
-    // blockIdx.y selects the plane; destination offsets are arbitrary, so 4-byte accesses.
     const uint32_t *src;
     uint32_t *dst;
     switch (blockIdx.y) {
@@ -500,14 +503,28 @@ __global__ void __launch_bounds__(BLOCK) join_copy_kernel(JoinPart part, float *
     default: src = part.rgbt; dst = ow; break;
     }
     dst += part.dst_offset;
-    size_t stride = (size_t)gridDim.x * BLOCK;
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < part.n; i += stride) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    if (VEC) {
+        const size_t n4 = part.n / 4;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) d4[i] = s4[i];
+        const size_t tail = n4 * 4 + threadIdx.x;
+        if (blockIdx.x == 0 && tail < part.n) dst[tail] = src[tail];   // up to three points
+    } else {
+        for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < part.n; i += stride) dst[i] = src[i];
+    }
 }
 
 void join_copy(const JoinPart &part, const DeviceSoA &dst, hipStream_t s) {
     if (!part.n) return;
-    unsigned gx = grid_for(part.n, BLOCK * 4);
-    CW_LAUNCH("join_copy", join_copy_kernel, dim3(gx, 4), dim3(BLOCK), 0, s, part, dst.x(), dst.y(), dst.z(), dst.rgbt());
+    if (part.dst_offset % 4 == 0) {   // source planes always start aligned; the destination does when the points before it come in fours
+        const unsigned gx = grid_for(part.n / 4 + 1, BLOCK * 2);
+        CW_LAUNCH("join_copy", join_copy_kernel<true>, dim3(gx, 4), dim3(BLOCK), 0, s, part, dst.x(), dst.y(), dst.z(), dst.rgbt());
+    } else {
+        const unsigned gx = grid_for(part.n, BLOCK * 4);
+        CW_LAUNCH("join_copy", join_copy_kernel<false>, dim3(gx, 4), dim3(BLOCK), 0, s, part, dst.x(), dst.y(), dst.z(), dst.rgbt());
+    }
 }
 
 }  // namespace k
