@@ -986,6 +986,59 @@ def test_hundred_million_points(gpu, oracle, synth):
     assert len(got) == len(exp) and got.tobytes() == exp.tobytes()
 
 
+def test_threads_mixed_chains(gpu, oracle, synth):
+    """Four threads run chains of filters on shared inputs for a while, dropping intermediate clouds at once (results
+    carry `ready` events, inputs `reader` events, downsamples alternate between two streams): every result must
+    be what the oracle says for that chain."""
+    import threading
+    pts, cs = synth(200000)
+    shared = make_cloud(gpu, pts, cs)
+    gpu.cwipc_hip_upload(shared)
+    bbox = [-0.2, 0.2, 0.0, 1.5, -0.3, 0.3]
+    d_oct, _ = oracle.downsample(pts, cs, 0.02)
+    d_grid, _ = oracle.downsample(pts, cs, -0.02)
+    exp = {
+        "tile_then_down": oracle.downsample(oracle.tilefilter(pts, 1), cs, 0.02)[0],
+        "down_then_crop": oracle.crop(d_oct, bbox),
+        "grid_then_tile": oracle.tilefilter(d_grid, 2),
+        "crop_join": oracle.join(oracle.crop(pts, bbox), oracle.tilefilter(pts, 2)),
+        "colormap_down": oracle.downsample(oracle.colormap(pts, 0x00ff0000, 0x00110000), cs, -0.02)[0],
+    }
+    errors = []
+
+    def close(got, want):
+        if len(got) != len(want):
+            return False
+        if not ((got['tile'] == want['tile']).all() and (got['r'] == want['r']).all() and (got['g'] == want['g']).all() and (got['b'] == want['b']).all()):
+            return False
+        return all(np.abs(got[f].astype(np.float64) - want[f]).max() <= 5e-5 for f in ('x', 'y', 'z')) if len(got) else True
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(25):
+                which = list(exp)[int(rng.integers(0, len(exp)))]
+                if which == "tile_then_down":
+                    out = gpu.cwipc_downsample(gpu.cwipc_tilefilter(shared, 1), 0.02)
+                elif which == "down_then_crop":
+                    out = gpu.cwipc_crop(gpu.cwipc_downsample(shared, 0.02), bbox)
+                elif which == "grid_then_tile":
+                    out = gpu.cwipc_tilefilter(gpu.cwipc_downsample(shared, -0.02), 2)
+                elif which == "crop_join":
+                    out = gpu.cwipc_join(gpu.cwipc_crop(shared, bbox), gpu.cwipc_tilefilter(shared, 2))
+                else:
+                    out = gpu.cwipc_downsample(gpu.cwipc_colormap(shared, 0x00ff0000, 0x00110000), -0.02)
+                if not close(out.get_numpy_array(), exp[which]):
+                    errors.append((seed, which))
+        except Exception as e:   # pragma: no cover
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors[:5]
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
