@@ -103,7 +103,9 @@ class SlotExchange:
         self._header_np = self._header.numpy()   # same memory: filled with one numpy assignment per frame
 
     def _resize(self, need: int) -> None:
-        cap = ((int(need * 1.25) + 4095) // 4096) * 4096
+        # room for 1/16 more than the largest cloud seen (frames of a stream are alike; every byte of a slot crosses
+        # the links, used or not), rounded up to 1024 rows
+        cap = ((need + need // 16 + 1023) // 1024) * 1024
         self.cap = max(cap, 4096)
         rows = self.cap + self.HEADER_ROWS
         self.send = torch.zeros((rows, 4), dtype=torch.int32, device=self.device)
