@@ -277,6 +277,7 @@ def main() -> None:
                 "fused_points": fused_points,
                 "input_copies_rotated": NCOPIES,
                 "inputs_resident_in_hbm": True,
+                **({"voxel_kernel_spare_cus": int(os.environ.get("CWIPC_SPARE_CUS", "0"))} if joining else {}),
             },
             "roofline": {
                 "bound": "hbm",
