@@ -225,7 +225,10 @@ def main() -> None:
 
     for i in range(args.warmup):
         step(i)
-    n_out = cwipc.cwipc_downsample(clouds[0], CELLSIZE).count()   # output points of this rank's own tile
+    # output points of this rank's own tile; four calls, so that both of the library's per-thread workspaces (used by
+    # alternate calls, 1.3 GB each) exist and know the size of their results whatever W is -- allocation is setup
+    for _ in range(4):
+        n_out = cwipc.cwipc_downsample(clouds[0], CELLSIZE).count()
 
     # ---- timed region ----
     fence()
