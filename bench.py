@@ -17,7 +17,8 @@ complete when the timed region ends).  For N > 1 the library is told to leave 24
 voxel kernel's persistent grid (CWIPC_SPARE_CUS, unless already set), so that the join's small kernels do not
 wait for a whole downsample.  Rehearsal knobs: CWIPC_BENCH_BACKEND=gloo (several ranks on one GPU, exchange
 staged through the host), CWIPC_BENCH_FORCE_JOIN=1 (N = 1 with a one-rank RCCL group: the whole N > 1 step
-but the wire), CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other).
+but the wire), CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other), CWIPC_BENCH_JOIN_ASYNC=0 (the
+worker waits for every frame's collective before it takes the next frame).
 
 One JSON line on rank 0.  `value` = points filtered by all ranks / wall time of the K timed steps
 (max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel
@@ -170,10 +171,15 @@ def main() -> None:
     pipelined = joining and os.environ.get("CWIPC_BENCH_PIPELINE", "1") != "0"
     joiner = None
     if joining:
-        from cwipc_util_amd.multigpu import join_across_ranks
+        from cwipc_util_amd.multigpu import join_across_ranks, JoinPipeline
     if pipelined:
         import queue
         import threading
+
+        FLUSH = object()
+        # CWIPC_BENCH_JOIN_ASYNC=0: the worker waits for every frame's collective before it takes the next frame;
+        # default: the collective of frame i is on the wire while frame i + 1 is packed (multigpu.JoinPipeline)
+        join_async = os.environ.get("CWIPC_BENCH_JOIN_ASYNC", "1") != "0"
 
         class Joiner:
             def __init__(self):
@@ -185,19 +191,29 @@ def main() -> None:
 
             def run(self):
                 torch.cuda.set_device(device_index)
+                pipe = JoinPipeline() if join_async else None
                 while True:
                     item = self.todo.get()
                     try:
                         if item is None:
                             return
-                        if self.error is None:
-                            self.last = join_across_ranks(item)
+                        if self.error is not None:
+                            continue
+                        if item is FLUSH:
+                            fused = pipe.flush() if pipe is not None else None
+                        elif pipe is not None:
+                            fused = pipe.submit(item)      # the fused cloud of the frame before
+                        else:
+                            fused = join_across_ranks(item)
+                        if fused is not None:
+                            self.last = fused
                     except BaseException as e:   # keep draining: the main thread must not block on a full queue
                         self.error = e
                     finally:
                         self.todo.task_done()
 
             def drain(self):
+                self.todo.put(FLUSH)
                 self.todo.join()
                 if self.error is not None:
                     raise self.error

@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks"]
+__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks", "JoinPipeline"]
 
 
 def tiles_of_rank(ntiles: int, rank: int, world: int) -> List[int]:
@@ -98,6 +98,8 @@ class SlotExchange:
         self.recv: Optional[torch.Tensor] = None
         self.collectives = 0   # for tests: how many collectives the last call needed
         self._overflow: Optional[torch.Tensor] = None
+        self._work = None        # the collective in flight (async launch)
+        self._n_local = 0
         # the two header rows are written on the host; page-locked when they have to travel to a GPU
         self._header = torch.zeros((self.HEADER_ROWS, 4), dtype=torch.int32, pin_memory=(device.type == "cuda"))
         self._header_np = self._header.numpy()   # same memory: filled with one numpy assignment per frame
@@ -142,6 +144,12 @@ class SlotExchange:
         """The collective itself: afterwards self.recv[r, HEADER_ROWS : HEADER_ROWS + counts[r]] holds rank r's points.
         Returns (min timestamp, min cellsize, counts); the library turns the slots into a cloud in one pass
         (cwipc_hip_from_device_slots), gather() concatenates them into a tensor."""
+        self.launch(n_local, timestamp, cellsize, has_cloud)
+        return self.finish()
+
+    def launch(self, n_local: int, timestamp: int, cellsize: float, has_cloud: bool = True, async_op: bool = False) -> None:
+        """First half of gather_slots(): header and collective go out; with async_op the call does not wait for the
+        collective (finish() does), so that the caller can pack the next frame into ANOTHER SlotExchange meanwhile."""
         import struct
         self.collectives = 0
         if self.cap == 0:
@@ -150,16 +158,28 @@ class SlotExchange:
         ts = int(timestamp) & 0xffffffffffffffff
         as_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
         cs_bits = struct.unpack("<i", struct.pack("<f", float(cellsize)))[0]
-        header = self._header
         self._header_np[:] = ((n_local, 1 if has_cloud else 0, cs_bits, 0), (as_i32(ts & 0xffffffff), as_i32(ts >> 32), 0, 0))
+        self._n_local = n_local
+        self._send_once(async_op)
+
+    def _send_once(self, async_op: bool) -> None:
+        self.send[:self.HEADER_ROWS].copy_(self._header, non_blocking=True)   # (the read-back of the headers in finish() waits for it)
+        rows = self.cap + self.HEADER_ROWS
+        if self.device.type == "cuda":
+            self._work = dist.all_gather_into_tensor(self.recv.view(self.world * rows, 4), self.send, group=self.group, async_op=async_op)
+        else:   # gloo: list form, same bytes
+            self._work = dist.all_gather([self.recv[r] for r in range(self.world)], self.send, group=self.group, async_op=async_op)
+        self.collectives += 1
+
+    def finish(self) -> Tuple[int, float, List[int]]:
+        """Second half of gather_slots(): waits for the collective, reads the headers, and gathers again (all ranks
+        alike) while some rank's cloud does not fit the slots."""
+        import struct
+        n_local = self._n_local
         while True:
-            self.send[:self.HEADER_ROWS].copy_(header, non_blocking=True)   # (the read-back of the headers below waits for it)
-            rows = self.cap + self.HEADER_ROWS
-            if self.device.type == "cuda":
-                dist.all_gather_into_tensor(self.recv.view(self.world * rows, 4), self.send, group=self.group)
-            else:   # gloo: list form, same bytes
-                dist.all_gather([self.recv[r] for r in range(self.world)], self.send, group=self.group)
-            self.collectives += 1
+            if self._work is not None:
+                self._work.wait()
+                self._work = None
             heads = self.recv[:, :self.HEADER_ROWS, :].cpu().numpy()   # (world, 2, 4) int32; waits for the collective
             counts = [int(v) for v in heads[:, 0, 0]]
             if max(counts) <= self.cap:
@@ -171,6 +191,7 @@ class SlotExchange:
             if keep is not None:
                 self.send[self.HEADER_ROWS:self.HEADER_ROWS + n_local] = keep
             self._adopt_overflow(n_local)
+            self._send_once(False)
         # min timestamp and min cellsize over the ranks that had a cloud (plain Python on 2 x world numbers)
         stamps, sizes = [], []
         for r in range(self.world):
@@ -189,17 +210,9 @@ class SlotExchange:
 _exchanges = {}
 
 
-def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
-    """All ranks call this with their (device-resident) cloud, or None for "no tile this frame";
-    every rank gets the fused cloud as a new cwipc_pointcloud_wrapper.  GPU only.  Frame after frame this
-    is one collective (SlotExchange); the library's SoA -> AoS kernel writes straight into the send slot."""
+def _pack(ex: SlotExchange, pc, dev: torch.device, staged: bool) -> Tuple[int, int, float, bool]:
+    """This rank's points into its send slot of `ex` (or its overflow buffer); returns (n, timestamp, cellsize, has_cloud)."""
     from . import util
-    dev = torch.device("cuda", torch.cuda.current_device())
-    staged = dist.get_backend(group) != "nccl"   # no device collectives (gloo: rehearsals on one GPU): slots live on the host
-    key = (id(group), dev.index, staged)
-    ex = _exchanges.get(key)
-    if ex is None:
-        ex = _exchanges[key] = SlotExchange(torch.device("cpu") if staged else dev, group)
     if pc is None:
         n, ts, cs, has = 0, 0, 0.0, False
     else:
@@ -211,13 +224,72 @@ def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
             util.cwipc_hip_copy_device_aos(pc, tmp.data_ptr(), n * 16)
             slot.copy_(tmp)
         else:
-            # (the slot is free: torch's last use of it, the previous frame's collective, was waited for when that
+            # (the slot is free: torch's last use of it, an earlier frame's collective, was waited for when that
             # frame's headers were read back; a new buffer is waited for where it is made)
             util.cwipc_hip_copy_device_aos(pc, slot.data_ptr(), n * 16)   # returns after the library's stream has finished
-    ts, cs, counts = ex.gather_slots(n, ts, cs, has)
+    return n, ts, cs, has
+
+
+def _unpack(ex: SlotExchange, counts: List[int], ts: int, cs: float, dev: torch.device, staged: bool):
+    """The receive buffer of `ex` as the fused cloud: slots -> planes in one pass of the library."""
+    from . import util
     recv = ex.recv.to(dev) if staged else ex.recv   # (world, cap + HEADER_ROWS, 4) int32
     if staged:
         torch.cuda.current_stream().synchronize()
     # (device path: reading the headers back has already waited for the collective that filled recv)
-    # slots -> planes of the fused cloud in one pass of the library (no concatenated copy in between)
     return util.cwipc_hip_from_device_slots(recv.data_ptr(), recv.shape[1], ex.HEADER_ROWS, counts, ts, cs)
+
+
+def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
+    """All ranks call this with their (device-resident) cloud, or None for "no tile this frame";
+    every rank gets the fused cloud as a new cwipc_pointcloud_wrapper.  GPU only.  Frame after frame this
+    is one collective (SlotExchange); the library's SoA -> AoS kernel writes straight into the send slot."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    staged = dist.get_backend(group) != "nccl"   # no device collectives (gloo: rehearsals on one GPU): slots live on the host
+    key = (id(group), dev.index, staged)
+    ex = _exchanges.get(key)
+    if ex is None:
+        ex = _exchanges[key] = SlotExchange(torch.device("cpu") if staged else dev, group)
+    n, ts, cs, has = _pack(ex, pc, dev, staged)
+    ts, cs, counts = ex.gather_slots(n, ts, cs, has)
+    return _unpack(ex, counts, ts, cs, dev, staged)
+
+
+class JoinPipeline:
+    """join_across_ranks for a stream of frames, one frame deep: submit(frame i + 1) packs that frame and sends its
+    collective off BEFORE it waits for the collective of frame i, so the time on the wire lies behind the packing of
+    the next frame (and behind whatever the caller does between two submits).  Two SlotExchange objects take the frames
+    in turn.  Every rank calls submit() with its cloud of the same frame (or None), in the same order; collectives stay
+    in step because each rank issues them in that one order, the repeats after an outgrown slot included."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.staged = dist.get_backend(group) != "nccl"
+        where = torch.device("cpu") if self.staged else self.dev
+        self.ex = [SlotExchange(where, group), SlotExchange(where, group)]
+        self.pending: Optional[int] = None   # index of the exchange whose collective is in flight
+        self.frames = 0
+
+    def submit(self, pc):
+        """Returns the fused cloud of the PREVIOUS frame (None for the first frame)."""
+        k = self.frames % 2
+        self.frames += 1
+        ex = self.ex[k]
+        n, ts, cs, has = _pack(ex, pc, self.dev, self.staged)
+        ex.launch(n, ts, cs, has, async_op=True)
+        out = self._finish(self.pending) if self.pending is not None else None
+        self.pending = k
+        return out
+
+    def flush(self):
+        """The fused cloud of the last frame submitted (None if there is none outstanding)."""
+        out = self._finish(self.pending) if self.pending is not None else None
+        self.pending = None
+        return out
+
+    def _finish(self, k: int):
+        ex = self.ex[k]
+        ts, cs, counts = ex.finish()
+        return _unpack(ex, counts, ts, cs, self.dev, self.staged)
+
+

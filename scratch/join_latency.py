@@ -16,6 +16,19 @@ sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): out = join_across_ranks(pc)
 sync(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
 print("join_across_ranks, 1 rank, %d points: %.1f us per frame" % (pc.count(), dt * 1e6), "fused", out.count())
+from cwipc_util_amd.multigpu import JoinPipeline
+pipe = JoinPipeline()
+for _ in range(20): pipe.submit(pc)
+sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): out2 = pipe.submit(pc)
+sync(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
+print("JoinPipeline.submit, 1 rank: %.1f us per frame" % (dt * 1e6), "fused", out2.count())
+if os.environ.get("JOIN_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(200): out2 = pipe.submit(pc)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(12)
 if os.environ.get("JOIN_PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()

@@ -151,3 +151,66 @@ def test_slot_exchange_stream_gloo(tmp_path, world):
     port = _free_port()
     mp.spawn(_stream_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _pipeline_worker(rank: int, world: int, port: int, result_dir: str):
+    """The exchange as JoinPipeline drives it: two SlotExchange objects take the frames in turn, the collective of
+    frame f + 1 is launched (async) before the one of frame f is waited for -- including frames that outgrow the slots,
+    whose repeat gathers are issued while the next frame's collective is in flight."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from cwipc_util_amd.multigpu import SlotExchange
+        from oracle import oracle
+        exs = [SlotExchange(torch.device("cpu")), SlotExchange(torch.device("cpu"))]
+        sizes = [3000, 3500, 0, 3200, 20000, 100, 22000, 0, 21000, 50, 30000]
+
+        def frame_tile(f, r):
+            n = sizes[f] + 137 * r
+            if sizes[f] == 0:
+                return oracle.empty(0), r != 0
+            pts, _ = oracle.synthetic(2 * n + 1000, 0.1 * f + r)
+            return pts[:n].copy(), True
+
+        def check(f, ex, ts, cs, counts):
+            exp, ets, ecs = None, None, None
+            for r in range(world):
+                p, h = frame_tile(f, r)
+                if not h:
+                    continue
+                exp = p if exp is None else oracle.join(exp, p)
+                ets = 1000 + 10 * f - r if ets is None else min(ets, 1000 + 10 * f - r)
+                ecs = np.float32(0.01 * (r + 1)) if ecs is None else min(ecs, np.float32(0.01 * (r + 1)))
+            if exp is None:
+                exp, ets, ecs = oracle.empty(0), 0, 0.0
+            parts = [ex.recv[r, ex.HEADER_ROWS:ex.HEADER_ROWS + counts[r]] for r in range(world) if counts[r]]
+            got = torch.cat(parts, dim=0).numpy().reshape(-1).view(exp.dtype) if parts else exp[:0]
+            assert counts == [len(frame_tile(f, r)[0]) for r in range(world)], (f, counts)
+            assert got.tobytes() == exp.tobytes(), f"frame {f}: fused cloud differs from the cwipc_join fold"
+            assert ts == ets and cs == pytest.approx(float(ecs), rel=0, abs=0), (f, ts, ets, cs, ecs)
+
+        pending = None
+        for f in range(len(sizes)):
+            ex = exs[f % 2]
+            pts, has = frame_tile(f, rank)
+            slot = ex.slot_points(len(pts))
+            if len(pts):
+                slot.copy_(torch.from_numpy(np.ascontiguousarray(pts).view(np.int32).reshape(-1, 4).copy()))
+            ex.launch(len(pts), 1000 + 10 * f - rank, 0.01 * (rank + 1), has, async_op=True)
+            if pending is not None:
+                pex = exs[pending % 2]
+                check(pending, pex, *pex.finish())
+            pending = f
+        pex = exs[pending % 2]
+        check(pending, pex, *pex.finish())
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_exchange_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
