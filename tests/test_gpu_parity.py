@@ -1039,6 +1039,35 @@ def test_threads_mixed_chains(gpu, oracle, synth):
     assert not errors, errors[:5]
 
 
+def test_join_pipeline_on_the_device_path(gpu, oracle, synth):
+    """join_across_ranks and JoinPipeline over RCCL with a one-rank group (the real device path: pack kernel into the
+    send slot, all_gather_into_tensor, slots -> cloud), frames of changing size including ones that outgrow the slots."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from cwipc_util_amd.multigpu import JoinPipeline, join_across_ranks
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        pts, cs = synth(100000)
+        frames = [pts[:3000], pts[:3500], pts[:0], pts[5000:5000 + 40000], pts[:100], pts[:90000], pts[200:700]]
+        clouds = [make_cloud(gpu, f, cs, 1000 + i) for i, f in enumerate(frames)]
+        for pc, f in zip(clouds, frames):
+            out = join_across_ranks(pc)
+            assert same(out.get_numpy_array(), f) and out.timestamp() == pc.timestamp()
+        pipe = JoinPipeline()
+        got = [pipe.submit(pc) for pc in clouds] + [pipe.flush()]
+        assert got[0] is None
+        for out, f, pc in zip(got[1:], frames, clouds):
+            assert same(out.get_numpy_array(), f) and out.timestamp() == pc.timestamp() and out.cellsize() == pc.cellsize()
+        assert pipe.flush() is None
+    finally:
+        dist.destroy_process_group()
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
