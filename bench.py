@@ -192,8 +192,12 @@ def main() -> None:
             def run(self):
                 torch.cuda.set_device(device_index)
                 pipe = JoinPipeline() if join_async else None
+                self.idle = self.busy = 0.0
                 while True:
+                    t_wait = time.perf_counter()
                     item = self.todo.get()
+                    t_got = time.perf_counter()
+                    self.idle += t_got - t_wait
                     try:
                         if item is None:
                             return
@@ -210,6 +214,7 @@ def main() -> None:
                     except BaseException as e:   # keep draining: the main thread must not block on a full queue
                         self.error = e
                     finally:
+                        self.busy += time.perf_counter() - t_got
                         self.todo.task_done()
 
             def drain(self):
@@ -224,7 +229,9 @@ def main() -> None:
     def step(i: int):
         out = cwipc.cwipc_downsample(clouds[i % NCOPIES], CELLSIZE)
         if joiner is not None:
+            t_put = time.perf_counter()
             joiner.todo.put(out)
+            joiner.blocked = getattr(joiner, "blocked", 0.0) + time.perf_counter() - t_put
             return out
         if joining:
             out = join_across_ranks(out)
@@ -253,6 +260,9 @@ def main() -> None:
         out = step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    if joiner is not None and os.environ.get("CWIPC_BENCH_JOIN_STATS") == "1":
+        print(f"[rank {rank}] since start: main thread blocked on the join queue {joiner.blocked * 1e3:.2f} ms, "
+              f"worker busy {joiner.busy * 1e3:.2f} ms, idle {joiner.idle * 1e3:.2f} ms; timed region {elapsed * 1e3:.2f} ms", file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
