@@ -671,6 +671,30 @@ extern "C" long cwipc_hip_copy_device_aos(cwipc_pointcloud *pc, void *dev_points
     return (long)dev->npoints;
 }
 
+// The same as a step of the CALLER's stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream): the
+// kernel is ordered behind whatever that stream holds and in front of what the caller puts there next (a
+// collective that sends the buffer), and the call does not wait for it.
+extern "C" long cwipc_hip_copy_device_aos_on_stream(cwipc_pointcloud *pc, void *dev_points, size_t size, void *stream) {
+    auto *ours = as_ours(pc);
+    if (!ours) return -1;
+    auto dev = ours->device_points();
+    if (!dev) return -1;
+    if (size < dev->npoints * sizeof(cwipc_point)) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip_copy_device_aos_on_stream", "buffer too small");
+        return -1;
+    }
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dev->npoints) {
+        dev->wait_on(s);                                       // the cloud may still be in the making on another stream
+        k::soa_to_aos(*dev, (cwipc_point *)dev_points, dev->npoints, s);
+        if (hipGetLastError() != hipSuccess) return -1;
+        dev->note_reader(s);                                   // ... and must stay until this kernel has read it
+    }
+    return (long)dev->npoints;
+}
+
 extern "C" cwipc_pointcloud *cwipc_hip_from_device_slots(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
                                                         const uint32_t *counts, uint64_t timestamp, float cellsize) {
     if (!device_available("cwipc_hip_from_device_slots")) return nullptr;
@@ -693,6 +717,40 @@ extern "C" cwipc_pointcloud *cwipc_hip_from_device_slots(const void *dev_slots, 
     if (!soa) return nullptr;
     if (total) k::slots_to_soa(dev_slots, nslots, slot_rows, header_rows, counts, *soa, c.stream);
     if (!c.sync()) return nullptr;   // the caller may reuse its receive buffer
+    auto *rv = new cwipc_hip_pointcloud();
+    rv->adopt_device(soa, timestamp, cellsize);
+    return rv;
+}
+
+// The same as a step of the caller's stream (see cwipc_hip_copy_device_aos_on_stream): behind the collective that fills
+// the receive buffer, in front of the next use the caller makes of that buffer on this stream; the new cloud carries a
+// `ready` event, the call does not wait.
+extern "C" cwipc_pointcloud *cwipc_hip_from_device_slots_on_stream(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
+                                                                  const uint32_t *counts, uint64_t timestamp, float cellsize, void *stream) {
+    if (!device_available("cwipc_hip_from_device_slots_on_stream")) return nullptr;
+    if (nslots < 0 || nslots > k::MAX_SLOTS || (nslots > 0 && (dev_slots == nullptr || counts == nullptr))) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip_from_device_slots_on_stream", "bad arguments (at most 64 slots)");
+        return nullptr;
+    }
+    size_t total = 0;
+    for (int i = 0; i < nslots; i++) {
+        if (header_rows + counts[i] > slot_rows) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip_from_device_slots_on_stream", "a slot's count exceeds its rows");
+            return nullptr;
+        }
+        total += counts[i];
+    }
+    if (total >= ((size_t)1 << 32)) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto soa = soa_alloc(total);
+    if (!soa) return nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (total) {
+        k::slots_to_soa(dev_slots, nslots, slot_rows, header_rows, counts, *soa, s);
+        if (hipGetLastError() != hipSuccess) return nullptr;
+        soa->mark_pending(s);
+    }
     auto *rv = new cwipc_hip_pointcloud();
     rv->adopt_device(soa, timestamp, cellsize);
     return rv;

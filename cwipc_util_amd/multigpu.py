@@ -210,6 +210,19 @@ class SlotExchange:
 _exchanges = {}
 
 
+_streams = {}
+
+
+def _torch_stream() -> int:
+    """torch's current stream on the current device as a hipStream_t (an integer).  The library's pack and unpack kernels
+    run as steps of it, where the collectives are ordered too, so that neither needs a wait on the host."""
+    idx = torch.cuda.current_device()
+    h = _streams.get(idx)
+    if h is None:
+        h = _streams[idx] = torch.cuda.current_stream().cuda_stream   # (looked up once: the lookup costs microseconds)
+    return h
+
+
 def _pack(ex: SlotExchange, pc, dev: torch.device, staged: bool) -> Tuple[int, int, float, bool]:
     """This rank's points into its send slot of `ex` (or its overflow buffer); returns (n, timestamp, cellsize, has_cloud)."""
     from . import util
@@ -224,20 +237,21 @@ def _pack(ex: SlotExchange, pc, dev: torch.device, staged: bool) -> Tuple[int, i
             util.cwipc_hip_copy_device_aos(pc, tmp.data_ptr(), n * 16)
             slot.copy_(tmp)
         else:
-            # (the slot is free: torch's last use of it, an earlier frame's collective, was waited for when that
-            # frame's headers were read back; a new buffer is waited for where it is made)
-            util.cwipc_hip_copy_device_aos(pc, slot.data_ptr(), n * 16)   # returns after the library's stream has finished
+            # a step of torch's stream: behind that stream's last use of the slot, in front of the collective that sends it
+            util.cwipc_hip_copy_device_aos(pc, slot.data_ptr(), n * 16, stream=_torch_stream())
     return n, ts, cs, has
 
 
 def _unpack(ex: SlotExchange, counts: List[int], ts: int, cs: float, dev: torch.device, staged: bool):
     """The receive buffer of `ex` as the fused cloud: slots -> planes in one pass of the library."""
     from . import util
-    recv = ex.recv.to(dev) if staged else ex.recv   # (world, cap + HEADER_ROWS, 4) int32
     if staged:
+        recv = ex.recv.to(dev)   # (world, cap + HEADER_ROWS, 4) int32
         torch.cuda.current_stream().synchronize()
-    # (device path: reading the headers back has already waited for the collective that filled recv)
-    return util.cwipc_hip_from_device_slots(recv.data_ptr(), recv.shape[1], ex.HEADER_ROWS, counts, ts, cs)
+        return util.cwipc_hip_from_device_slots(recv.data_ptr(), recv.shape[1], ex.HEADER_ROWS, counts, ts, cs)
+    # device path: a step of torch's stream, behind the collective that filled recv (its headers have been read back) and
+    # in front of the next collective into the same buffer; the fused cloud carries an event, nobody waits here
+    return util.cwipc_hip_from_device_slots(ex.recv.data_ptr(), ex.recv.shape[1], ex.HEADER_ROWS, counts, ts, cs, stream=_torch_stream())
 
 
 def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):

@@ -204,6 +204,8 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_copy_device_aos': ([cwipc_pointcloud_p, _c.c_void_p, _c.c_size_t], _c.c_long),
     'cwipc_hip_from_device_aos': ([_c.c_void_p, _c.c_size_t, _c.c_uint64, _c.c_float], cwipc_pointcloud_p),
     'cwipc_hip_from_device_slots': ([_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_size_t, _c.POINTER(_c.c_uint32), _c.c_uint64, _c.c_float], cwipc_pointcloud_p),
+    'cwipc_hip_from_device_slots_on_stream': ([_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_size_t, _c.POINTER(_c.c_uint32), _c.c_uint64, _c.c_float, _c.c_void_p], cwipc_pointcloud_p),
+    'cwipc_hip_copy_device_aos_on_stream': ([cwipc_pointcloud_p, _c.c_void_p, _c.c_size_t, _c.c_void_p], _c.c_long),
     'cwipc_hip_colorize': ([cwipc_pointcloud_p, _c.c_double, _c.c_void_p, _c.c_void_p], cwipc_pointcloud_p),
     'cwipc_hip_join_multi': ([_c.POINTER(cwipc_pointcloud_p), _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_tilefilter_masked': ([cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
@@ -874,17 +876,27 @@ def cwipc_hip_from_device_aos(dev_ptr: int, npoint: int, timestamp: int, cellsiz
     return _wrap_filter_result('cwipc_hip_from_device_aos', rv)
 
 
-def cwipc_hip_from_device_slots(dev_ptr: int, slot_rows: int, header_rows: int, counts: List[int], timestamp: int, cellsize: float) -> cwipc_pointcloud_wrapper:
+def cwipc_hip_from_device_slots(dev_ptr: int, slot_rows: int, header_rows: int, counts: List[int], timestamp: int, cellsize: float,
+                                stream: Optional[int] = None) -> cwipc_pointcloud_wrapper:
     """New cloud from the receive buffer of an all-gather at a DEVICE address: len(counts) slots of slot_rows
-    16-byte rows, the records of slot s in rows [header_rows, header_rows + counts[s]); slot order = point order."""
+    16-byte rows, the records of slot s in rows [header_rows, header_rows + counts[s]); slot order = point order.
+    stream (a hipStream_t as an integer, e.g. torch.cuda.current_stream().cuda_stream): run as a step of that stream
+    and return without waiting."""
     arr = (ctypes.c_uint32 * len(counts))(*counts)
-    rv = cwipc_util_dll_load().cwipc_hip_from_device_slots(dev_ptr, len(counts), slot_rows, header_rows, arr, timestamp, cellsize)
+    if stream is None:
+        rv = cwipc_util_dll_load().cwipc_hip_from_device_slots(dev_ptr, len(counts), slot_rows, header_rows, arr, timestamp, cellsize)
+    else:
+        rv = cwipc_util_dll_load().cwipc_hip_from_device_slots_on_stream(dev_ptr, len(counts), slot_rows, header_rows, arr, timestamp, cellsize, stream)
     return _wrap_filter_result('cwipc_hip_from_device_slots', rv)
 
 
-def cwipc_hip_copy_device_aos(pc: cwipc_pointcloud_wrapper, dev_ptr: int, size: int) -> int:
-    """Interleave the cloud into a DEVICE buffer of `size` bytes; returns the number of points."""
-    n = cwipc_util_dll_load().cwipc_hip_copy_device_aos(pc.as_cwipc_p(), dev_ptr, size)
+def cwipc_hip_copy_device_aos(pc: cwipc_pointcloud_wrapper, dev_ptr: int, size: int, stream: Optional[int] = None) -> int:
+    """Interleave the cloud into a DEVICE buffer of `size` bytes; returns the number of points.  stream (a hipStream_t
+    as an integer): run as a step of that stream and return without waiting."""
+    if stream is None:
+        n = cwipc_util_dll_load().cwipc_hip_copy_device_aos(pc.as_cwipc_p(), dev_ptr, size)
+    else:
+        n = cwipc_util_dll_load().cwipc_hip_copy_device_aos_on_stream(pc.as_cwipc_p(), dev_ptr, size, stream)
     if n < 0:
         raise CwipcError("cwipc_hip_copy_device_aos failed")
     return n

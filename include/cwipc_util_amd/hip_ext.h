@@ -44,6 +44,11 @@ _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_aos(const void *dev_p
    slot s in rows [header_rows, header_rows + counts[s]); the new cloud holds them in slot order.  counts is a host array. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_slots(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
                                                                  const uint32_t *counts, uint64_t timestamp, float cellsize);
+/* Both as steps of the CALLER's stream (hipStream_t; e.g. the stream its collectives are ordered on): no wait inside, the
+   kernel runs behind what the stream holds and in front of what the caller enqueues next; the new cloud carries an event. */
+_CWIPC_UTIL_EXPORT long cwipc_hip_copy_device_aos_on_stream(cwipc_pointcloud *pc, void *dev_points, size_t size, void *stream);
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_slots_on_stream(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
+                                                                           const uint32_t *counts, uint64_t timestamp, float cellsize, void *stream);
 
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */
