@@ -24,49 +24,69 @@ class cwipc_pointcloud_abstract(ABC):
 
 
 class cwipc_source_abstract(ABC):
-    @abstractmethod
-    def free(self) -> None: ...
+    """Something that hands out point clouds one at a time (a generator, a decoder, a synchroniser)."""
 
     @abstractmethod
-    def eof(self) -> bool: ...
+    def free(self) -> None:
+        """Give the native object back; the wrapper is unusable afterwards."""
 
     @abstractmethod
-    def available(self, wait: bool) -> bool: ...
+    def eof(self) -> bool:
+        """True once no further cloud will ever come."""
 
     @abstractmethod
-    def get(self) -> Optional[cwipc_pointcloud_abstract]: ...
+    def available(self, wait: bool) -> bool:
+        """Is a cloud ready to be taken?  With wait=True the call may block until one is (or until end of stream)."""
 
     @abstractmethod
-    def statistics(self) -> None: ...
+    def get(self) -> Optional[cwipc_pointcloud_abstract]:
+        """The next cloud, or None when there is none to be had."""
+
+    @abstractmethod
+    def statistics(self) -> None:
+        """Print whatever the source counted while it ran."""
 
 
 class cwipc_activesource_abstract(cwipc_source_abstract):
-    @abstractmethod
-    def reload_config(self, config: Union[str, bytes, None]) -> Any: ...
+    """A source with a life cycle of its own (cameras, the synthetic generator): it is started and stopped, can be
+    configured, knows its tiles, and may attach metadata to the clouds it produces."""
 
     @abstractmethod
-    def get_config(self) -> bytes: ...
+    def start(self) -> bool:
+        """Begin producing; False if that is not possible."""
 
     @abstractmethod
-    def start(self) -> bool: ...
+    def stop(self) -> None:
+        """Stop producing."""
 
     @abstractmethod
-    def stop(self) -> None: ...
+    def reload_config(self, config: Union[str, bytes, None]) -> Any:
+        """Apply a new configuration (JSON text, a file name, or None for the default)."""
 
     @abstractmethod
-    def seek(self, timestamp: int) -> bool: ...
+    def get_config(self) -> bytes:
+        """The configuration in force, as JSON."""
 
     @abstractmethod
-    def request_metadata(self, name: str) -> None: ...
+    def seek(self, timestamp: int) -> bool:
+        """Move a recorded stream to the given timestamp; False where that means nothing."""
 
     @abstractmethod
-    def is_metadata_requested(self, name: str) -> bool: ...
+    def maxtile(self) -> int:
+        """Number of tile descriptions get_tileinfo_dict() can answer for."""
 
     @abstractmethod
-    def auxiliary_operation(self, op: str, inbuf: bytes, outbuf: bytearray) -> bool: ...
+    def get_tileinfo_dict(self, tilenum: int) -> cwipc_tileinfo_dict:
+        """Description of one tile: its normal, its camera, how many cameras contribute, the camera mask."""
 
     @abstractmethod
-    def maxtile(self) -> int: ...
+    def request_metadata(self, name: str) -> None:
+        """Ask for the named per-frame metadata to be attached to every cloud from now on."""
 
     @abstractmethod
-    def get_tileinfo_dict(self, tilenum: int) -> cwipc_tileinfo_dict: ...
+    def is_metadata_requested(self, name: str) -> bool:
+        """Has request_metadata(name) been called?"""
+
+    @abstractmethod
+    def auxiliary_operation(self, op: str, inbuf: bytes, outbuf: bytearray) -> bool:
+        """Source-specific side channel: operation name, input bytes, room for the answer; False if unknown."""
