@@ -1789,7 +1789,37 @@ struct Workspace {
 
 // Two workspaces per thread, used by alternate calls, each with its own stream (ThreadCtx::stream / stream_alt):
 // a call's finalize kernel, still running when the call returns, works on grids the next call does not touch.
-thread_local Workspace t_ws[2];
+// The workspaces of threads that have ended wait here for the next thread (1.3 GB each: a program that starts a
+// thread per frame must not allocate and free that much every time).
+std::mutex g_ws_pool_mutex;
+std::vector<Workspace *> *g_ws_pool = new std::vector<Workspace *>();   // never destroyed: threads may end after the statics
+
+struct WorkspaceLease {
+    Workspace *ws[2] = {nullptr, nullptr};
+    Workspace &get(int which) {
+        if (!ws[which]) {
+            const int dev = current_device();
+            std::lock_guard<std::mutex> lock(g_ws_pool_mutex);
+            for (size_t i = 0; i < g_ws_pool->size(); i++) {
+                if ((*g_ws_pool)[i]->device == dev) {   // one that already holds grids on this device
+                    ws[which] = (*g_ws_pool)[i];
+                    g_ws_pool->erase(g_ws_pool->begin() + (long)i);
+                    break;
+                }
+            }
+            if (!ws[which]) ws[which] = new Workspace();
+        }
+        return *ws[which];
+    }
+    ~WorkspaceLease() {
+        // thread exit: a finalize kernel of this thread's last call may still be using a workspace
+        if (ws[0] || ws[1]) (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lock(g_ws_pool_mutex);
+        for (int i = 0; i < 2; i++)
+            if (ws[i]) g_ws_pool->push_back(ws[i]);
+    }
+};
+thread_local WorkspaceLease t_ws;
 thread_local int t_ws_next = 0;
 
 // For the duration of a call: the thread's current stream is the one of the workspace in use.
@@ -1899,7 +1929,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     const size_t n = src.npoints;
     const int which = t_ws_next;
     t_ws_next ^= 1;
-    Workspace &ws = t_ws[which];
+    Workspace &ws = t_ws.get(which);
     StreamOfWorkspace on_its_stream(c, which);
     src.wait_on(c.stream);   // (the caller ordered the thread's first stream behind the input's producer; this may be the second)
     if (n >= ((size_t)1 << 31)) {
