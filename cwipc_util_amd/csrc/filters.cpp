@@ -170,7 +170,7 @@ extern "C" cwipc_pointcloud *cwipc_tilemap(cwipc_pointcloud *pc, uint8_t map[256
     if (!src) return nullptr;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
-    auto dst = soa_alloc(src->npoints);
+    auto dst = soa_with_new_rgbt(src);   // the coordinates do not change: the result holds the very same planes
     if (!dst) return nullptr;
     // the 256-byte table travels through the per-thread pinned words
     memcpy(c.host_words, map, 256);
@@ -190,7 +190,7 @@ extern "C" cwipc_pointcloud *cwipc_colormap(cwipc_pointcloud *pc, uint32_t clear
     if (!src) return nullptr;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
-    auto dst = soa_alloc(src->npoints);
+    auto dst = soa_with_new_rgbt(src);   // the coordinates do not change: the result holds the very same planes
     if (!dst) return nullptr;
     k::map_color_bits(*src, *dst, clearBits, setBits, c.stream);
     if (!c.sync()) return nullptr;
@@ -264,7 +264,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double wei
     if (!src) return nullptr;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
-    auto dst = soa_alloc(src->npoints);
+    auto dst = soa_with_new_rgbt(src);   // the coordinates do not change: the result holds the very same planes
     if (!dst) return nullptr;
     const int ndoubles = 1025 + 256;
     double *host_table = (double *)c.staging(ndoubles * sizeof(double));

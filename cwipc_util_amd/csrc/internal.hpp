@@ -126,12 +126,22 @@ bool profiling_enabled();
 // point storage
 // ---------------------------------------------------------------------------
 
-// Device representation: four planes in one pool block, each plane `stride`
-// elements long (stride = npoints rounded up to 256, so every plane starts on a
-// 1 KiB boundary and a full wave step of 256 points can always be loaded).  rgbt = r | g<<8 | b<<16 | tile<<24, i.e. the last four
-// bytes of a cwipc_point read as one little-endian word.
+// A pool block that several clouds may hold (clouds are immutable: a filter that changes colours or tiles only
+// gives its result the input's coordinate planes instead of copying them).
+struct PlaneBlock {
+    void *ptr = nullptr;
+    explicit PlaneBlock(void *p) : ptr(p) {}
+    PlaneBlock(const PlaneBlock &) = delete;
+    PlaneBlock &operator=(const PlaneBlock &) = delete;
+    ~PlaneBlock() { if (ptr) pool_free(ptr); }
+};
+
+// Device representation: four planes, each `stride` elements long (stride = npoints rounded up to 256, so every
+// plane starts on a 1 KiB boundary and a full wave step of 256 points can always be loaded): x, y, z in one pool
+// block, rgbt in another.  rgbt = r | g<<8 | b<<16 | tile<<24, i.e. the last four bytes of a cwipc_point read as
+// one little-endian word.
 struct DeviceSoA {
-    void *base = nullptr;
+    std::shared_ptr<PlaneBlock> xyz_block, rgbt_block;
     size_t npoints = 0;
     size_t stride = 0;
     int device = 0;
@@ -157,10 +167,10 @@ struct DeviceSoA {
     mutable std::mutex readers_mutex;
     mutable std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
     void note_reader(hipStream_t consumer) const;
-    float *x() const { return (float *)base; }
-    float *y() const { return (float *)base + stride; }
-    float *z() const { return (float *)base + 2 * stride; }
-    uint32_t *rgbt() const { return (uint32_t *)base + 3 * stride; }
+    float *x() const { return (float *)xyz_block->ptr; }
+    float *y() const { return (float *)xyz_block->ptr + stride; }
+    float *z() const { return (float *)xyz_block->ptr + 2 * stride; }
+    uint32_t *rgbt() const { return (uint32_t *)rgbt_block->ptr; }
     ~DeviceSoA() {
         if (ready) {
             (void)hipEventSynchronize(ready);   // normally long complete
@@ -170,10 +180,12 @@ struct DeviceSoA {
             (void)hipEventSynchronize(r.second);
             event_put(r.second);
         }
-        if (base) pool_free(base);
+        // (the blocks go back to the pool when the last cloud that holds them has come this far)
     }
 };
 std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints);
+// A cloud with `src`'s coordinates (the very planes) and colour / tile words of its own, still to be written.
+std::shared_ptr<DeviceSoA> soa_with_new_rgbt(const std::shared_ptr<DeviceSoA> &src);
 
 // Host memory for point buffers: page-locked and pooled when a GPU is there (the DMA engines then
 // read and write it directly, no staging copy), plain malloc otherwise.

@@ -327,7 +327,8 @@ struct MapArgs {
 //   [1025,1281) valid[t]  (non-zero = the colour map has an entry for tile t)
 static constexpr int COLORIZE_DOUBLES = 1025 + 256;
 
-template <int KIND>
+// COPY_XYZ = false: the result shares the input's coordinate planes (soa_with_new_rgbt), only the words are touched.
+template <int KIND, bool COPY_XYZ>
 __global__ void __launch_bounds__(BLOCK) map_kernel(MapArgs a, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                                                    const uint32_t *__restrict__ rgbt, float *__restrict__ ox, float *__restrict__ oy,
                                                    float *__restrict__ oz, uint32_t *__restrict__ ow, size_t n, const void *__restrict__ table) {
@@ -349,15 +350,17 @@ __global__ void __launch_bounds__(BLOCK) map_kernel(MapArgs a, const float *__re
         if (v < nvec) {
             uint4 t = ((const uint4 *)rgbt)[v];
             w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
-            ((float4 *)ox)[v] = ((const float4 *)x)[v];
-            ((float4 *)oy)[v] = ((const float4 *)y)[v];
-            ((float4 *)oz)[v] = ((const float4 *)z)[v];
+            if (COPY_XYZ) {
+                ((float4 *)ox)[v] = ((const float4 *)x)[v];
+                ((float4 *)oy)[v] = ((const float4 *)y)[v];
+                ((float4 *)oz)[v] = ((const float4 *)z)[v];
+            }
         } else {
             cnt = (int)(n - nvec * 4);   // ragged tail, handled by one lane
             for (int j = 0; j < cnt; j++) {
                 size_t i = nvec * 4 + j;
                 w[j] = rgbt[i];
-                ox[i] = x[i]; oy[i] = y[i]; oz[i] = z[i];
+                if (COPY_XYZ) { ox[i] = x[i]; oy[i] = y[i]; oz[i] = z[i]; }
             }
         }
 #pragma unroll
@@ -398,8 +401,13 @@ template <int KIND>
 static void launch_map(const char *name, const DeviceSoA &src, const DeviceSoA &dst, MapArgs a, const void *table, hipStream_t s) {
     size_t n = src.npoints;
     if (!n) return;
-    CW_LAUNCH(name, (map_kernel<KIND>), dim3(grid_for(n / 4 + 1, BLOCK)), dim3(BLOCK), 0, s, a, src.x(), src.y(), src.z(), src.rgbt(), dst.x(),
-              dst.y(), dst.z(), dst.rgbt(), n, table);
+    if (dst.x() == src.x()) {   // shared coordinate planes
+        CW_LAUNCH(name, (map_kernel<KIND, false>), dim3(grid_for(n / 4 + 1, BLOCK)), dim3(BLOCK), 0, s, a, src.x(), src.y(), src.z(), src.rgbt(),
+                  dst.x(), dst.y(), dst.z(), dst.rgbt(), n, table);
+    } else {
+        CW_LAUNCH(name, (map_kernel<KIND, true>), dim3(grid_for(n / 4 + 1, BLOCK)), dim3(BLOCK), 0, s, a, src.x(), src.y(), src.z(), src.rgbt(),
+                  dst.x(), dst.y(), dst.z(), dst.rgbt(), n, table);
+    }
 }
 
 void map_tile(const DeviceSoA &src, const DeviceSoA &dst, const uint8_t *dev_map256, hipStream_t s) {

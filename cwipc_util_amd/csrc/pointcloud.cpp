@@ -66,8 +66,22 @@ std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints) {
     soa->stride = ((npoints + 255) / 256) * 256;
     if (soa->stride == 0) soa->stride = 256;
     soa->device = current_device();
-    soa->base = pool_alloc(soa->stride * 16);
-    if (!soa->base) return nullptr;
+    void *xyz = pool_alloc(soa->stride * 12), *rgbt = pool_alloc(soa->stride * 4);
+    if (xyz) soa->xyz_block = std::make_shared<PlaneBlock>(xyz);
+    if (rgbt) soa->rgbt_block = std::make_shared<PlaneBlock>(rgbt);
+    if (!xyz || !rgbt) return nullptr;
+    return soa;
+}
+
+std::shared_ptr<DeviceSoA> soa_with_new_rgbt(const std::shared_ptr<DeviceSoA> &src) {
+    auto soa = std::make_shared<DeviceSoA>();
+    soa->npoints = src->npoints;
+    soa->stride = src->stride;
+    soa->device = src->device;
+    soa->xyz_block = src->xyz_block;
+    void *rgbt = pool_alloc(soa->stride * 4);
+    if (!rgbt) return nullptr;
+    soa->rgbt_block = std::make_shared<PlaneBlock>(rgbt);
     return soa;
 }
 
