@@ -132,6 +132,9 @@ extern "C" cwipc_pointcloud *cwipc_tilefilter(cwipc_pointcloud *pc, int tile) {
     std::unique_ptr<cwipc_hip_pointcloud> keep;
     auto src = device_input("cwipc_tilefilter", pc, keep);
     if (!src) return nullptr;
+    // tile 0 keeps every point (reference :296): the result is the same cloud -- clouds are immutable, so it holds
+    // the very same planes instead of a copy of them
+    if (tile == 0) return wrap(src, pc->timestamp(), pc->cellsize());
     k::Predicate p{};
     p.mode = 0;
     p.tile = tile;
@@ -206,7 +209,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_transform(cwipc_pointcloud *pc, const dou
     if (!src) return nullptr;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
-    auto dst = soa_alloc(src->npoints);
+    auto dst = soa_with_new_xyz(src);   // colours and tiles do not change: the result holds the very same words
     if (!dst) return nullptr;
     double m[12];
     for (int r = 0; r < 3; r++)
@@ -224,7 +227,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_offset_scale(cwipc_pointcloud *pc, double
     if (!src) return nullptr;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
-    auto dst = soa_alloc(src->npoints);
+    auto dst = soa_with_new_xyz(src);   // colours and tiles do not change: the result holds the very same words
     if (!dst) return nullptr;
     double m[12] = {scale, 0, 0, x, 0, 0, 0, y, 0, 0, 0, z};
     k::map_affine(*src, *dst, m, 1, c.stream);

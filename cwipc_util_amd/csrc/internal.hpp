@@ -186,6 +186,8 @@ struct DeviceSoA {
 std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints);
 // A cloud with `src`'s coordinates (the very planes) and colour / tile words of its own, still to be written.
 std::shared_ptr<DeviceSoA> soa_with_new_rgbt(const std::shared_ptr<DeviceSoA> &src);
+// ... and the other way round: `src`'s colour / tile words, coordinate planes of its own.
+std::shared_ptr<DeviceSoA> soa_with_new_xyz(const std::shared_ptr<DeviceSoA> &src);
 
 // Host memory for point buffers: page-locked and pooled when a GPU is there (the DMA engines then
 // read and write it directly, no staging copy), plain malloc otherwise.

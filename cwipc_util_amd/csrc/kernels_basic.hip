@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(BLOCK) affine_kernel(AffineArgs a, const float
             rz = __dmul_rn(__dadd_rn(pz, a.m[11]), a.m[0]);
         }
         ox[i] = (float)rx; oy[i] = (float)ry; oz[i] = (float)rz;
-        ow[i] = rgbt[i];
+        if (ow != rgbt) ow[i] = rgbt[i];   // (a result that shares the input's colour / tile words has nothing to copy)
     }
 }
 

@@ -73,6 +73,18 @@ std::shared_ptr<DeviceSoA> soa_alloc(size_t npoints) {
     return soa;
 }
 
+std::shared_ptr<DeviceSoA> soa_with_new_xyz(const std::shared_ptr<DeviceSoA> &src) {
+    auto soa = std::make_shared<DeviceSoA>();
+    soa->npoints = src->npoints;
+    soa->stride = src->stride;
+    soa->device = src->device;
+    soa->rgbt_block = src->rgbt_block;
+    void *xyz = pool_alloc(soa->stride * 12);
+    if (!xyz) return nullptr;
+    soa->xyz_block = std::make_shared<PlaneBlock>(xyz);
+    return soa;
+}
+
 std::shared_ptr<DeviceSoA> soa_with_new_rgbt(const std::shared_ptr<DeviceSoA> &src) {
     auto soa = std::make_shared<DeviceSoA>();
     soa->npoints = src->npoints;
