@@ -304,6 +304,16 @@ extern "C" cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int np
         }
         total += src[i]->npoints;
     }
+    uint64_t ts = pcs[0]->timestamp();
+    float cellsize = pcs[0]->cellsize();
+    for (int i = 1; i < npc; i++) {
+        ts = std::min(ts, pcs[i]->timestamp());
+        cellsize = std::min(cellsize, pcs[i]->cellsize());
+    }
+    // all points in one of the inputs (the others are empty): the result holds that input's planes, nothing is copied
+    for (int i = 0; i < npc; i++) {
+        if (src[i]->npoints == total && total > 0) return wrap(src[i], ts, cellsize);
+    }
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     auto dst = soa_alloc(total);
@@ -315,12 +325,6 @@ extern "C" cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int np
         off += src[i]->npoints;
     }
     if (!c.sync()) return nullptr;
-    uint64_t ts = pcs[0]->timestamp();
-    float cellsize = pcs[0]->cellsize();
-    for (int i = 1; i < npc; i++) {
-        ts = std::min(ts, pcs[i]->timestamp());
-        cellsize = std::min(cellsize, pcs[i]->cellsize());
-    }
     return wrap(dst, ts, cellsize);
 }
 
