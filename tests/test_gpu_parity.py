@@ -1073,6 +1073,45 @@ def test_join_pipeline_on_the_device_path(gpu, oracle, synth):
         dist.destroy_process_group()
 
 
+def test_results_that_share_planes_outlive_their_input(gpu, oracle, synth):
+    """Results of colormap / tilemap / transform / tilefilter(0) / a join with empty partners hold planes of their input
+    instead of copies (clouds are immutable); freeing the input must leave them whole, and the input whole when they go."""
+    import gc
+    pts, cs = synth(50000)
+    m = np.eye(4); m[0, 3] = 0.25
+
+    def fresh():
+        pc = make_cloud(gpu, pts, cs, 7)
+        gpu.cwipc_hip_upload(pc, drop_host_copy=True)
+        return pc
+
+    makers = {
+        "colormap": (lambda pc: gpu.cwipc_colormap(pc, 0x0000ff00, 0x00003300), oracle.colormap(pts, 0x0000ff00, 0x00003300)),
+        "tilemap": (lambda pc: gpu.cwipc_tilemap(pc, {1: 4, 2: 8}), oracle.tilemap(pts, bytes([0, 4, 8] + [0] * 253))),
+        "transform": (lambda pc: gpu.cwipc_transform(pc, m), oracle.transform(pts, m)),
+        "tilefilter0": (lambda pc: gpu.cwipc_tilefilter(pc, 0), pts),
+        "join_with_empty": (lambda pc: gpu.cwipc_join(gpu.cwipc_from_points([], 3), pc), pts),
+    }
+    for name, (make, exp) in makers.items():
+        pc = fresh()
+        out = make(pc)
+        pc.free(force=True)
+        del pc
+        gc.collect()
+        filler = fresh()                      # takes whatever the freed input gave back to the pool
+        assert same(out.get_numpy_array(), exp), name
+        # the other way round: the result goes, the input stays
+        pc = fresh()
+        out = make(pc)
+        out.free(force=True)
+        del out
+        gc.collect()
+        filler2 = make_cloud(gpu, exp, cs)
+        gpu.cwipc_hip_upload(filler2)
+        assert same(pc.get_numpy_array(), pts), name
+        del filler, filler2
+
+
 def test_no_leaks_over_many_calls(gpu, synth):
     """Device pool, pinned pool and object counters stay put over a few hundred filter calls."""
     import gc
