@@ -74,8 +74,11 @@ def measured_traffic(n_points: int, kernel: str):
     return None, None
 
 
-def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 12.0):
-    """Time the oracle's downsample on the host (1 thread).  Test infrastructure used as the CPU baseline."""
+def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 10.0):
+    """Time the oracle's downsample on the host.  Test infrastructure used as the CPU baseline.  Two legs: one thread
+    (the like-for-like figure: the reference filter is single-threaded, no OpenMP or threads in src/cwipc_filters.cpp),
+    and every core of this host running the same single-threaded job on a cloud each (a stream of frames is what
+    parallelises on the CPU side too; `cores` says how many)."""
     from oracle import oracle
     try:
         lib = oracle.load(native=True)   # -march=native copy built on this host
@@ -84,18 +87,23 @@ def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 12.0)
         lib = oracle.load()
         kind_note = "gcc -O3"
     import ctypes
+
+    def one_run(out, ocs):
+        t0 = time.perf_counter()
+        m = lib.oracle_downsample(points.ctypes.data, len(points), pc_cellsize, CELLSIZE, out.ctypes.data, len(out),
+                                  ctypes.addressof(ocs), None, None)
+        assert m > 0
+        return time.perf_counter() - t0, int(m)
+
     out = np.zeros(len(points), dtype=oracle.POINT_DTYPE)
     ocs = ctypes.c_float(0)
     times = []
     t_end = time.perf_counter() + budget_s
     while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
-        t0 = time.perf_counter()
-        m = lib.oracle_downsample(points.ctypes.data, len(points), pc_cellsize, CELLSIZE, out.ctypes.data, len(out),
-                                  ctypes.addressof(ocs), None, None)
-        times.append(time.perf_counter() - t0)
-        assert m > 0
+        dt, m = one_run(out, ocs)
+        times.append(dt)
     best = float(np.median(times))
-    return {
+    result = {
         "value": len(points) / best / 1e6,
         "unit": "Mpoints/s",
         "cores": 1,
@@ -103,6 +111,86 @@ def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 12.0)
         "sample": f"full workload ({len(points)} points), median of {len(times)} runs, {kind_note}; "
                   "C restatement of pcl::VoxelGrid + octree split, not PCL",
         "outputs": int(m),
+    }
+    # all cores: one single-threaded job per core at the same time (ctypes releases the GIL), three rounds
+    from concurrent.futures import ThreadPoolExecutor
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    bufs = [(np.zeros(len(points), dtype=oracle.POINT_DTYPE), ctypes.c_float(0)) for _ in range(cores)]
+    rounds = []
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            list(pool.map(lambda b: one_run(*b), bufs))
+            rounds.append(time.perf_counter() - t0)
+    result["all_cores"] = {
+        "value": cores * len(points) / float(np.median(rounds)) / 1e6,
+        "unit": "Mpoints/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cores} concurrent single-threaded runs of the full workload (one cloud per core), median of 3 rounds: "
+                  "aggregate throughput of a stream of frames, not the latency of one",
+    }
+    return result
+
+
+def bench_config4(cwipc, rank: int, world: int, steps: int, warmup: int, fence, join_across_ranks):
+    """BASELINE configs[3]: the 8-tile capture (8 x synthetic(2 000 000), camera mask 1 << i, rotated i x 45 degrees),
+    tile t on rank t mod world; per tile tilefilter(1 << t) -> downsample(0.01); the local results joined (n-ary join),
+    then the all-gatherv join across ranks.  N = 1 runs all eight tiles one after the other.  Strong scaling: the job is
+    the same 8 tiles whatever N is."""
+    from cwipc_util_amd.capture import capture_tile, per_tile_chain
+    from cwipc_util_amd.multigpu import tiles_of_rank
+    NT, NP = 8, 2_000_000
+    mine = tiles_of_rank(NT, rank, world)
+    tiles = []
+    for t in mine:
+        pc = capture_tile(NP, t, NT, timestamp=1000 + t)
+        cwipc.cwipc_hip_upload(pc, drop_host_copy=True)
+        tiles.append((t, pc))
+    n_tile = tiles[0][1].count() if tiles else 0
+
+    def frame():
+        outs = [per_tile_chain(pc, t, CELLSIZE) for t, pc in tiles]
+        local = cwipc.cwipc_join_multi(outs) if outs else None
+        return join_across_ranks(local) if join_across_ranks is not None else local
+
+    for _ in range(warmup):
+        frame()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fused = frame()
+    fence()
+    elapsed = time.perf_counter() - t0
+    return elapsed, n_tile, (fused.count() if fused is not None else 0), len(mine)
+
+
+def bench_config3(cwipc, pc, n: int, runs: int = 5):
+    """BASELINE configs[2]: cwipc_remove_outliers(k = 16, sigma = 1.0, perTile = false) on the 10 M-point cloud.
+    Algorithmic bytes: 16 N + 8 N (the d_i round trip) + 16 N_keep."""
+    sync = cwipc.util.cwipc_util_dll_load().cwipc_hip_synchronize
+    kept = cwipc.cwipc_remove_outliers(pc, 16, 1.0, False).count()   # warm-up: grid workspaces
+    sync()
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        cwipc.cwipc_remove_outliers(pc, 16, 1.0, False)
+        sync()
+        times.append(time.perf_counter() - t0)
+    with cwipc.cwipc_hip_profile() as prof:
+        cwipc.cwipc_remove_outliers(pc, 16, 1.0, False)
+    kernel_ms = sum(v[0] for v in prof.kernels.values())
+    ms = float(np.median(times)) * 1e3
+    alg = 16 * n + 8 * n + 16 * kept
+    return {
+        "workload": "cwipc_synthetic(10000000) -> cwipc_remove_outliers(16, 1.0, false) [BASELINE configs[2]]",
+        "ms_per_call": ms, "value": n / ms / 1e3, "unit": "Mpoints/s", "kept": kept, "runs": runs,
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_call": alg, "all_kernels_ms_per_call": kernel_ms,
+                     "achieved": alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel_ms > 0 else None,
+                     "note": "no target (SURVEY section 8d): the k-NN pass is latency / LDS bound, not HBM bound"},
+        "kernels": {k: {"ms_total": v[0], "launches": v[1]} for k, v in prof.kernels.items()},
     }
 
 
@@ -113,6 +201,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--npoints", type=int, default=NPOINTS_ARG)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 8-tile capture sub-record")
+    ap.add_argument("--no-config3", action="store_true", help="skip the outlier-removal sub-record (N = 1 only)")
+    ap.add_argument("--config4-steps", type=int, default=30)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -282,6 +373,30 @@ def main() -> None:
 
     traffic, traffic_src = measured_traffic(n, dominant)
 
+    # ---- sub-records: BASELINE configs[3] (8-tile capture, strong scaling over ranks) and configs[2] (outlier removal) ----
+    config4 = None
+    if not args.no_config4:
+        if joiner is not None:
+            joiner.drain()
+        c4_elapsed, c4_ntile, c4_fused, c4_mine = bench_config4(cwipc, rank, world, args.config4_steps, 3, fence,
+                                                                join_across_ranks if joining else None)
+        if dist is not None:
+            t = torch.tensor([c4_elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c4_elapsed = float(t.item())
+        config4 = {
+            "workload": "8 x cwipc_synthetic(2000000, angle = i pi/4), mask 1 << i, rotated i x 45 deg about Y; tile t on rank t mod N: "
+                        "cwipc_tilefilter(1 << t) -> cwipc_downsample(0.01), n-ary join"
+                        + (f", all-gatherv join over {world} ranks" if joining else "") + " [BASELINE configs[3]]",
+            "value": 8 * c4_ntile * args.config4_steps / c4_elapsed / 1e6 if c4_ntile else None,
+            "unit": "Mpoints/s", "scaling": "strong", "n_gpus": world, "steps": args.config4_steps,
+            "ms_per_frame": c4_elapsed / args.config4_steps * 1e3, "points_per_tile": c4_ntile, "tiles_on_rank0": c4_mine,
+            "fused_points": c4_fused, "inputs_resident_in_hbm": True,
+        }
+    config3 = None
+    if world == 1 and not args.no_config3 and args.npoints == NPOINTS_ARG:
+        config3 = bench_config3(cwipc, clouds[0], n)
+
     if rank == 0:
         result = {
             "metric": "Mpoints/s filtered (voxel downsample, 10M-pt synthetic) + achieved HBM GB/s",
@@ -325,6 +440,10 @@ def main() -> None:
             },
             "kernels": kernels,
         }
+        if config4 is not None:
+            result["config4"] = config4
+        if config3 is not None:
+            result["config3"] = config3
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pts, pc_cellsize)
         print(json.dumps(result))

@@ -89,6 +89,7 @@ std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, 
     }
     if (!seen) ok = c.sync() && ok;
     if (!ok || (uint32_t)(*word >> 32) != tag) {
+        (void)c.sync();   // `dst` goes back to the pool: nothing may still be writing it
         hip_failed(hipGetLastError(), "compaction", __FILE__, __LINE__);
         return nullptr;
     }
@@ -377,7 +378,9 @@ std::shared_ptr<DeviceSoA> sor_once(const DeviceSoA &src, int k, float stddev_mu
     double *thr_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(dist) + ((src.npoints * sizeof(float) + 127) & ~(size_t)127));
     std::shared_ptr<DeviceSoA> out;
     if (sor_mean_distances(src, k, dist) && sor_threshold_device(dist, src.npoints, stddev_mul, thr_dev)) out = sor_select(src, dist, 0.0, thr_dev);
-    else (void)tctx().sync();
+    // every failure exit: kernels that read or write `dist` may still be in flight, and the block goes back to a pool
+    // other threads allocate from
+    if (!out) (void)tctx().sync();
     pool_free(dist);
     return out;
 }

@@ -210,17 +210,12 @@ class SlotExchange:
 _exchanges = {}
 
 
-_streams = {}
-
-
 def _torch_stream() -> int:
     """torch's current stream on the current device as a hipStream_t (an integer).  The library's pack and unpack kernels
-    run as steps of it, where the collectives are ordered too, so that neither needs a wait on the host."""
-    idx = torch.cuda.current_device()
-    h = _streams.get(idx)
-    if h is None:
-        h = _streams[idx] = torch.cuda.current_stream().cuda_stream   # (looked up once: the lookup costs microseconds)
-    return h
+    run as steps of it, where the collectives are ordered too, so that neither needs a wait on the host.  Looked up on
+    every call: the caller may be inside `with torch.cuda.stream(s)` or on another thread than last time, and a stale
+    handle would put the two kernels on a stream the collective is not ordered against."""
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _pack(ex: SlotExchange, pc, dev: torch.device, staged: bool) -> Tuple[int, int, float, bool]:

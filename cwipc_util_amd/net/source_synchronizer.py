@@ -200,7 +200,12 @@ class _Synchronizer(threading.Thread, cwipc_activesource_abstract):
                 latency = int(time.time() * 1000) - result.timestamp()
                 print(f'synchronizer: produced pointcloud ts={result.timestamp()} with {result.count()} points, latency={latency} ms, '
                       f'qlen={self.output_queue.qsize()}', flush=True)
-            self.output_queue.put(result)
+            while self.running:   # (a plain put() would keep stop() waiting for ever behind a full queue)
+                try:
+                    self.output_queue.put(result, timeout=0.05)
+                    break
+                except queue.Full:
+                    continue
         if self.verbose: print("synchronizer: thread exiting", flush=True)
         self.running = False
         try:

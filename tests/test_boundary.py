@@ -295,3 +295,20 @@ def test_capturer_registry(cwipc):
         cwipc.cwipc_capturer('{"type": "othercam"}')
     with pytest.raises(cwipc.CwipcError, match="no supported cameras"):
         cwipc.cwipc_capturer("auto")
+
+
+def test_pcl_aware_caller_sees_an_empty_shared_ptr(cwipc, tmp_path):
+    """a sibling library compiled against api_pcl.h calls access_pcl_pointcloud() through the vtable and
+    receives a shared_ptr by value in a hidden return slot (reference include/cwipc_util/api_pcl.h:74, api.h:270-276).
+    tests/abi/pcl_aware_caller.cpp is such a caller (std::shared_ptr in place of the PCL type); it also calls the virtuals
+    on either side of that slot."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ here")
+    libdir = os.path.join(ROOT, "cwipc_util_amd", "lib")
+    exe = str(tmp_path / "pcl_aware_caller")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi", "pcl_aware_caller.cpp"),
+                    "-o", exe, "-L" + libdir, "-lcwipc_util", "-Wl,-rpath," + libdir], check=True)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
