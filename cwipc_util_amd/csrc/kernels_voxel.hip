@@ -197,18 +197,23 @@ void first_box(const double p[3], double res, double mn[3], double mx[3], int &d
 
 // The octree key of a coordinate, floor((p - min) / resolution) in double (genOctreeKeyforPoint),
 // is monotone in p: "key >= m" is a threshold test p >= T(m).  Smallest float that passes.
+// Found by bisection over the ordered floats: near zero the double sum p - min absorbs thousands of float steps
+// (a face through a first point with a coordinate of -5e-17 -- a cloud rotated by 270 degrees -- sits ~1e28 float steps
+// away from (float)(min + m * res)), so no fixed-width search around that value is safe.
 float leaf_threshold(double mn0, double res, int m) {
     const double md = (double)m;
-    float c = (float)(mn0 + md * res);
-    for (int i = 0; i < 8; i++) {
-        const float p = nextafterf(c, -INFINITY);
-        if (floor(((double)p - mn0) / res) >= md) c = p; else break;
+    const auto passes = [&](float p) { return floor(((double)p - mn0) / res) >= md; };
+    // floats as integers in their numeric order
+    const auto to_ord = [](float f) { int32_t b; memcpy(&b, &f, 4); return b >= 0 ? (int64_t)b : -(int64_t)(b & 0x7fffffff); };
+    const auto from_ord = [](int64_t o) { int32_t b = o >= 0 ? (int32_t)o : (int32_t)(0x80000000u | (uint32_t)(-o)); float f; memcpy(&f, &b, 4); return f; };
+    int64_t lo = to_ord(-FLT_MAX), hi = to_ord(FLT_MAX);   // invariant: lo fails, hi passes (if they do at all)
+    if (passes(from_ord(lo))) return -FLT_MAX;
+    if (!passes(from_ord(hi))) return INFINITY;
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (passes(from_ord(mid))) hi = mid; else lo = mid;
     }
-    for (int i = 0; i < 8; i++) {
-        if (floor(((double)c - mn0) / res) >= md) break;
-        c = nextafterf(c, INFINITY);
-    }
-    return c;
+    return from_ord(hi);
 }
 
 // ---------------------------------------------------------------------------

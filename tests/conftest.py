@@ -16,6 +16,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def cwipc():
     """The product package, with the HIP library built if it is missing."""
+    # torch first: it brings its own copy of the HIP runtime, and a process can hold only one.  Loaded after
+    # libcwipc_util.so (which is linked against /opt/rocm's), torch finds "No HIP GPUs"; the other way round both share
+    # torch's copy.  (INTEGRATION.md section 3 states the same rule for applications that use both.)
+    import torch  # noqa: F401
     import cwipc_util_amd
     try:
         cwipc_util_amd.cwipc_util_dll_load()

@@ -350,6 +350,26 @@ def test_downsample_shifted_and_rotated(gpu, oracle, synth):
         check_downsample(gpu, oracle, p[rng.permutation(len(p))], cs, 0.02)
 
 
+def test_downsample_leaf_face_through_a_first_point_near_zero(gpu, oracle, synth):
+    """The octree's first box puts a leaf face through the first point (PCL: min = p - resolution after getKeyBitSize).
+    When that coordinate is a rounding residue like -5e-17 (a cloud rotated by 270 degrees), the double sum p - min
+    swallows ~1e28 float steps around the face: the face threshold has to be searched over the whole float line
+    (found by the BASELINE config 4 test: tile 6 came out 229 points short)."""
+    pts = oracle.empty(3)
+    pts['x'], pts['y'] = -0.27, 0.001
+    pts['z'] = [-4.9759e-17, -0.005, 0.003]
+    got, exp = check_downsample(gpu, oracle, pts, 0.0, 0.01)
+    assert len(got) == 3          # voxel z = -1 is cut by the face at z ~ 0: one output on either side
+    for first in (-4.9759e-17, 4.9759e-17, -1e-30, 1e-30, -0.0, -1.4e-45):
+        for other in (-0.005, -2e-17, 2e-17, -1e-40, 0.0):
+            pts['z'] = [first, other, 0.003]
+            check_downsample(gpu, oracle, pts, 0.0, 0.01)
+    from cwipc_util_amd.capture import rotation_about_y
+    base, cs = synth(100000)
+    for quarter in (1, 2, 3):
+        check_downsample(gpu, oracle, oracle.transform(base, rotation_about_y(quarter * np.pi / 2)), cs, 0.01)
+
+
 def test_downsample_points_on_voxel_faces(gpu, oracle):
     """Coordinates that are exact multiples of the cell size: fl(x * inv_leaf) puts them a hair
     below their voxel's origin, i.e. the offset inside the voxel is slightly negative."""
