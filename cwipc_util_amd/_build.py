@@ -56,7 +56,7 @@ def _newest_header_mtime() -> float:
     for root in (SRC_DIR, os.path.join(REPO_DIR, "include")):
         for dirpath, _dirs, files in os.walk(root):
             for f in files:
-                if f.endswith((".h", ".hpp")):
+                if f.endswith((".h", ".hpp", ".inc")):
                     newest = max(newest, os.path.getmtime(os.path.join(dirpath, f)))
     return newest
 
@@ -76,7 +76,16 @@ def _compile(src: str, force: bool, header_mtime: float) -> str:
     return obj_path
 
 
-def build(force: bool = False, jobs: int = 6) -> str:
+def build(force: bool = False, jobs: int = 6, debug_knobs: bool = False) -> str:
+    """debug_knobs: a second copy of the library with -DCWIPC_DEBUG_KNOBS (stage switches for timing experiments; results are
+    wrong when they are set) in scratch/lib_dbg/ -- select it with CWIPC_LIBRARY_DIR.  The shipped library has none of them."""
+    global OBJ_DIR, LIB_DIR, LIB_PATH
+    if debug_knobs:
+        OBJ_DIR = os.path.join(SRC_DIR, "build_dbg")
+        LIB_DIR = os.path.join(REPO_DIR, "scratch", "lib_dbg")
+        LIB_PATH = os.path.join(LIB_DIR, "libcwipc_util.so")
+        if "-DCWIPC_DEBUG_KNOBS" not in COMMON_FLAGS:
+            COMMON_FLAGS.append("-DCWIPC_DEBUG_KNOBS")
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     header_mtime = _newest_header_mtime()
@@ -91,4 +100,4 @@ def build(force: bool = False, jobs: int = 6) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, debug_knobs="--debug-knobs" in sys.argv))

@@ -58,6 +58,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <cfloat>
+#include <type_traits>
 #include <cmath>
 
 namespace cwipc_amd {
@@ -85,18 +86,12 @@ constexpr int RANK_THREADS = 256;
 constexpr int RANK_SEGS = 16;                  // a few leaves hold all the work: many slices per leaf for enough workgroups
 constexpr int SEG_WORDS = (BITWORDS + RANK_SEGS - 1) / RANK_SEGS;                 // 615
 constexpr int WORDS_PER_THREAD = (SEG_WORDS + RANK_THREADS - 1) / RANK_THREADS;   // 3
-constexpr float FIX_ONE_F = 4194304.0f;        // 2^22 fixed-point units per voxel edge
-// Offsets are summed with a per-point bias so that the packed sums never borrow.  fl(f * inv_leaf)
-// may land |g| * 2^-23 voxels away from f / leaf, so an offset lies in [-|g| / 2, 2^22 + |g| / 2] units:
-// the normal scale (2^22 units per voxel, bias 2^21) holds for clouds within 4e6 voxels of the origin;
-// beyond that the host reruns with the wide scale (2^14 units, bias 2^19: +-32 voxels, and still far
-// finer than the spacing of fp32 coordinates out there).
-constexpr float FIX_ONE_WIDE_F = 16384.0f;
-constexpr uint32_t Q_BIAS = 1u << 21, Q_BIAS_WIDE = 1u << 19;
-constexpr float G_CHECK = 4.0e6f, G_CHECK_WIDE = 33554432.0f;
 constexpr int RECORD_WORDS = 8;                // 64-byte records: sx sy sz cr gb tlo thi tor
 constexpr int FACES = 128;                     // leaf faces per axis with a precomputed threshold
 constexpr int FACE_BACK = 63;                  // the table starts 63 faces below the first point's leaf
+// threshold table in 32-bit words: [3][FACES] thresholds T (float), [3][FACES] Tv (float: lower bound of the voxel above
+// the one T lies in), [3][FACES] tf (int: index of the voxel T lies in); the general kernel reads the first part only
+constexpr int FT_T = 0, FT_TV = 3 * FACES, FT_TF = 6 * FACES, FACE_TABLE_WORDS = 9 * FACES;
 
 enum : uint32_t {
     ERR_RANGE = 1,           // voxel index outside +-2^26, or leaf index outside +-2^20
@@ -108,7 +103,6 @@ enum : uint32_t {
     ERR_CELL_RANGE = 64,
     ERR_LIST_FULL = 128,
     ERR_LOCAL_LEAVES = 512,  // a workgroup met more leaves than its local leaf table holds: host reruns with global leaf ids in the hot loop
-    ERR_FIXED_RANGE = 256,   // coordinates beyond 4e6 voxels: host reruns with the wide fixed-point scale
 };
 
 // control block, 32-bit words in device memory
@@ -126,8 +120,9 @@ struct VoxParams {
     uint32_t nranges;       // number of wave ranges = waves in the K1 grid
     float inv_leaf;         // 1 / leaf in fp32, as pcl::VoxelGrid::setLeafSize
     float leaf;
-    float fix_scale;        // 2^22 / leaf (fp32)
     double leaf_d;
+    double vox_unit;        // 1 / inv_leaf: a voxel index times this is the voxel's lower corner
+    double q_unit;          // 1 / (inv_leaf * 2^23): what one unit of the offset sums is worth
     double res;             // octree resolution (double)(float)(64 * leaf)
     // anchor (host): first octree box and the voxel index of its lower corner
     double mn0[3], mx0[3];
@@ -216,6 +211,21 @@ float leaf_threshold(double mn0, double res, int m) {
     return from_ord(hi);
 }
 
+// Smallest float whose voxel index floor(fl(p * inv_leaf)) exceeds `voxel` (fp32 product, as the kernels compute it).
+float voxel_upper_bound(float inv_leaf, int voxel) {
+    const auto passes = [&](float p) { return floorf(p * inv_leaf) > (float)voxel; };
+    const auto to_ord = [](float f) { int32_t b; memcpy(&b, &f, 4); return b >= 0 ? (int64_t)b : -(int64_t)(b & 0x7fffffff); };
+    const auto from_ord = [](int64_t o) { int32_t b = o >= 0 ? (int32_t)o : (int32_t)(0x80000000u | (uint32_t)(-o)); float f; memcpy(&f, &b, 4); return f; };
+    int64_t lo = to_ord(-FLT_MAX), hi = to_ord(FLT_MAX);
+    if (passes(from_ord(lo))) return -FLT_MAX;
+    if (!passes(from_ord(hi))) return INFINITY;
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (passes(from_ord(mid))) hi = mid; else lo = mid;
+    }
+    return from_ord(hi);
+}
+
 // ---------------------------------------------------------------------------
 // global side: leaf lookup, record updates
 // ---------------------------------------------------------------------------
@@ -290,15 +300,12 @@ struct LdsTable {
 // The slim parameter block of K1 (kernel arguments live in SGPRs; K1 is short of them).
 struct K1Params {
     uint32_t n, per_wave;
-    float inv_leaf, leaf, fix_scale;
+    float inv_leaf;
     int ib0, ib1, ib2;
     int fb0, fb1, fb2;
     uint32_t leaf_mask, list_cap, ablate;
     uint32_t local_leaves;   // 1: keys carry workgroup-local leaf slots (no global memory access in the hot loop)
     uint32_t want_list;      // 1: the touched records are listed in W.occupied (plain grid: the sort needs them); 0: only counted
-    uint32_t q_bias;    // per-point bias of the offset sums
-    float q_round;      // q_bias + 0.5 (the offset is biased and rounded by one fma, then truncated)
-    float g_check;      // |coordinate * inv_leaf| a wave may see at this scale (inf: no limit)
     double mn0[3];      // MODE 2 only
     double res;
 };
@@ -390,12 +397,11 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
             uint32_t s_key = 0;
             if (s_rec != 0xffffffffu && sub < 7) {
                 const uint32_t cnt = s_cr >> 16;
-                const long long bias = (long long)cnt * P.q_bias;
                 unsigned long long val;
                 switch (sub) {
-                case 0: val = (unsigned long long)((long long)s_qx - bias); break;
-                case 1: val = (unsigned long long)((long long)s_qy - bias); break;
-                case 2: val = (unsigned long long)((long long)s_qz - bias); break;
+                case 0: val = s_qx; break;
+                case 1: val = s_qy; break;
+                case 2: val = s_qz; break;
                 case 3: val = u64_of(s_cr & 0xffffu, cnt); break;                 // count << 32 | sum r
                 case 4: val = u64_of(s_gb & 0xffffu, s_gb >> 16); break;         // sum g << 32 | sum b
                 case 5:   // tile bits 0-3 as 16-bit contribution counters
@@ -475,12 +481,22 @@ struct PointOut {
     bool seen;      // the point exists and is finite
 };
 
-// One coordinate: cell c inside the leaf grid, leaf (n or l), biased offset q.
+// Position inside the voxel as an integer: prod = fl(p * inv_leaf) is the number pcl::VoxelGrid floors, so
+// prod - floor(prod) in [0, 1) is where the point sits in its voxel, in voxel units.  Adding 1.0 rounds that to a
+// multiple of 2^-23 (ties to even, unbiased) and leaves it in the mantissa: q in [0, 2^23].  One v_fract and one add;
+// the centroid is rebuilt as (voxel + sum q / (n 2^23)) / inv_leaf in f64 by the emit kernels (VoxParams::vox_unit, q_unit).
+// Both accumulate kernels (the fast one and the general one) use this very function: their integer sums are identical.
+constexpr uint32_t Q_ONE_BITS = 0x3f800000u;   // bits of 1.0f
+__device__ __forceinline__ float voxel_fract(float prod) { return __builtin_amdgcn_fractf(prod); }
+__device__ __forceinline__ uint32_t voxel_offset(float prod) { return __float_as_uint(__fadd_rn(voxel_fract(prod), 1.0f)) - Q_ONE_BITS; }
+
+// One coordinate: cell c inside the leaf grid, leaf (n or l), offset q inside the voxel.
 // MODE 0: plain grid (bricks on the voxel lattice); 1: octree leaves by face thresholds; 2: octree leaves by f64 division.
 template <int MODE>
 __device__ __forceinline__ void axis_cell(const K1Params &P, int ib, const FaceCache &fc, int axis, float f, int &u, int &n, int &l, int &c,
                                           uint32_t &q) {
-    const float g = floorf(__fmul_rn(f, P.inv_leaf));   // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
+    const float prod = __fmul_rn(f, P.inv_leaf);
+    const float g = floorf(prod);                        // pcl::VoxelGrid: floor(p * inverse_leaf_size), fp32 product
     const int ti = (int)g;                               // v_cvt_i32_f32 (saturating; non-finite points are masked by the caller)
     if (MODE == 1) {
         // leaf = (face mc - 1) + [f >= T(mc)] + [f >= T(mc + 1)], valid while the voxel lies between faces mc - 1/2 and mc + 3/2
@@ -493,8 +509,7 @@ __device__ __forceinline__ void axis_cell(const K1Params &P, int ib, const FaceC
         else l = (int)floor(((double)f - P.mn0[axis]) / P.res);   // genOctreeKeyforPoint
         c = t - 64 * l + 2;
     }
-    // offset inside the voxel in fixed-point units, biased and rounded half up: (p - g * leaf) * scale + bias + 0.5, truncated
-    q = (uint32_t)(int)fmaf(fmaf(-g, P.leaf, f), P.fix_scale, P.q_round);
+    q = voxel_offset(prod);
 }
 
 template <int MODE>
@@ -528,7 +543,8 @@ __device__ __forceinline__ PointOut point_key_lookup(const K1Params &P, const fl
     bool ok = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float g = floorf(__fmul_rn(f[a], P.inv_leaf));
+        const float prod = __fmul_rn(f[a], P.inv_leaf);
+        const float g = floorf(prod);
         const int t = (int)g - ib[a];
         const int m = (t + 32) >> 6;                         // the face nearest to this voxel
         const unsigned i = (unsigned)(m - fb[a]);
@@ -538,7 +554,7 @@ __device__ __forceinline__ PointOut point_key_lookup(const K1Params &P, const fl
         const float tlo = faces[a * FACES + ii], thi = faces[a * FACES + ii + 1];
         l[a] = m - 1 + (f[a] >= tlo ? 1 : 0) + (f[a] >= thi ? 1 : 0);
         c[a] = t - 64 * l[a] + 2;
-        q[a] = (uint32_t)(int)fmaf(fmaf(-g, P.leaf, f[a]), P.fix_scale, P.q_round);
+        q[a] = voxel_offset(prod);
     }
     o.l0 = l[0]; o.l1 = l[1]; o.l2 = l[2];
     o.q0 = q[0]; o.q1 = q[1]; o.q2 = q[2];
@@ -584,6 +600,12 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
                                                                      const float *__restrict__ z, const uint32_t *__restrict__ rgbt, VoxWork W) {
     extern __shared__ __align__(16) unsigned char k1_smem[];
     LdsTable &L = *reinterpret_cast<LdsTable *>(k1_smem);
+    // stage switches for timing experiments exist in -DCWIPC_DEBUG_KNOBS builds only (results are wrong when set)
+#ifdef CWIPC_DEBUG_KNOBS
+    const uint32_t ablate = P.ablate;
+#else
+    constexpr uint32_t ablate = 0u;
+#endif
 
     const int lane = threadIdx.x & 63;
     // everything that is the same for the whole wave lives in SGPRs
@@ -603,7 +625,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     uint4 cw = make_uint4(0, 0, 0, 0);
     if (npts > 0) { cx = vx[0]; cy = vy[0]; cz = vz[0]; cw = vw[0]; }
 
-    if (!(P.ablate & 128u))
+    if (!(ablate & 128u))
     for (int i = threadIdx.x; i < LTAB; i += K1_THREADS) {
         L.key[i] = KEY_EMPTY; L.tile[i] = 0;
         L.a[i] = 0; L.b[i] = 0; L.c[i] = 0; L.d[i] = 0;
@@ -637,7 +659,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
         const int left = npts - off - lane * 4;   // points of this lane that exist: min(left, 4)
 
-        if (P.ablate & 1u) {   // diagnostics: loads only
+        if (ablate & 1u) {   // diagnostics: loads only
             bn0 = fminf(bn0, cx.x + cx.y + cx.z + cx.w + cy.x + cy.y + cy.z + cy.w + cz.x + cz.y + cz.z + cz.w + __uint_as_float(cw.x ^ cw.y ^ cw.z ^ cw.w));
             cx = nx; cy = ny; cz = nz; cw = nw;
             continue;
@@ -743,7 +765,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             }
         }
 
-        if (P.ablate & 2u) {   // diagnostics: loads + per-point arithmetic only
+        if (ablate & 2u) {   // diagnostics: loads + per-point arithmetic only
             bx0 = fmaxf(bx0, __uint_as_float((o0.key ^ o1.key ^ o2.key ^ o3.key) + (o0.q0 + o1.q1 + o2.q2 + o3.q0 + o0.nn + o1.nn + o2.nn + o3.nn) +
                                               (uint32_t)(o0.l0 + o1.l1 + o2.l2)));
             cx = nx; cy = ny; cz = nz; cw = nw;
@@ -751,7 +773,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
 
         // ---- leaf ids ----
-        if (MODE == 1 && !slow_step && !(P.ablate & 64u)) {
+        if (MODE == 1 && !slow_step && !(ablate & 64u)) {
             // The leaf of a point is one of the 27 positions around the cached faces (nn); this wave's table
             // in LDS says which leaf that is.  A plain LDS read per point; the lookup behind it runs once
             // per position (and again after the face caches moved).
@@ -792,7 +814,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             // KEY_EMPTY stays all ones
             o0.key |= s0 << CELL_BITS; o1.key |= s1 << CELL_BITS; o2.key |= s2 << CELL_BITS; o3.key |= s3 << CELL_BITS;
         }
-        if ((MODE != 1 || __builtin_expect(slow_step, 0)) && !(P.ablate & 64u)) {
+        if ((MODE != 1 || __builtin_expect(slow_step, 0)) && !(ablate & 64u)) {
             // the points carry leaf lattice coordinates here; one leaf and its name are cached in scalar registers
             int mm = 0;
             mm |= o0.key != KEY_EMPTY ? (o0.l0 ^ cl0) | (o0.l1 ^ cl1) | (o0.l2 ^ cl2) : 0;
@@ -886,7 +908,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         const uint32_t prev_xkey = (uint32_t)dpp_shr<1>((int)k3);   // 0 in the first lane of a row of 16
         const int flag0 = (single && (lane & 7) != 0 && prev_xkey == k0) ? 0 : 1;   // 1: the lane starts a chain
         int flag = flag0;
-        if (!(P.ablate & 16u)) {
+        if (!(ablate & 16u)) {
             scan_step<1>(X, flag);
             scan_step<2>(X, flag);
             scan_step<4>(X, flag);
@@ -899,7 +921,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         const uint32_t next_k0 = (uint32_t)dpp_shl<1>((int)k0);
         const bool tail_final = row_last | (next_flag0 != 0);
         const bool take = !row_last & (next_multi != 0) & (next_k0 == k3);
-        if (!(P.ablate & 32u)) {
+        if (!(ablate & 32u)) {
             const int tm = take ? -1 : 0;
             X.qx += (uint32_t)(dpp_shl<1>((int)H.qx) & tm);
             X.qy += (uint32_t)(dpp_shl<1>((int)H.qy) & tm);
@@ -915,7 +937,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         // what a lane has to insert, in this order: its chain (if it ends here), its head (if nobody took
         // it), the run(s) between head and tail.  Round 0 takes the first of them, which is all there is in
         // most steps of a scan-ordered cloud.
-        if (!(P.ablate & 4u)) {
+        if (!(ablate & 4u)) {
             const bool have_t = tail_final & (k3 != KEY_EMPTY);
             const bool have_h = multi & !head_taken & (k0 != KEY_EMPTY);
             Run32 M1, M2;   // nb == 2: one run in between (everything but head and tail); nb == 3: points 1 and 2
@@ -956,7 +978,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         cx = nx; cy = ny; cz = nz; cw = nw;
     }
 
-    if (P.ablate & 128u) { if (bn0 == 1.2345f) W.bboxes[0] = bn0 + bx0; return; }   // diagnostics: no epilogue at all
+    if (ablate & 128u) { if (bn0 == 1.2345f) W.bboxes[0] = bn0 + bx0; return; }   // diagnostics: no epilogue at all
     // ---- errors of this wave, bounding box of its range (input of the octree replay) ----
     {
         for (int s = 32; s > 0; s >>= 1) err |= (uint32_t)__shfl_xor((int)err, s, 64);
@@ -972,8 +994,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             if (lane == 0) {
                 W.bboxes[(size_t)range * 6 + a] = vlo;
                 W.bboxes[(size_t)range * 6 + 3 + a] = vhi;
-                // too far out for this fixed-point scale (the pass is discarded, its records cleaned)
-                if (vlo <= vhi && fmaxf(fabsf(vlo), fabsf(vhi)) * P.inv_leaf >= P.g_check) atomicOr(&W.ctrl[C_ERR], ERR_FIXED_RANGE);
             }
         }
     }
@@ -1000,7 +1020,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     for (int it = 0; it < FLUSH_ITERS; it++) {
         const int e = (threadIdx.x >> 3) + it * (K1_THREADS / 8);
         uint32_t k = L.key[e];
-        if (P.ablate & 8u) k = KEY_EMPTY;
+        if (ablate & 8u) k = KEY_EMPTY;
         if (P.local_leaves && k != KEY_EMPTY) {
             const uint32_t gid = L.leaf_gid[k >> CELL_BITS];
             k = gid == 0xffffffffu ? KEY_EMPTY : ((gid << CELL_BITS) | (k & ((1u << CELL_BITS) - 1)));
@@ -1011,12 +1031,12 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         used += sub == 0 ? 1u : 0u;
         const uint32_t t = L.tile[e];
         const unsigned long long ea = L.a[e], eb = L.b[e], ec = L.c[e], ed = L.d[e];
-        const unsigned long long cnt = ed & 0xffffull, bias = cnt * P.q_bias;
+        const unsigned long long cnt = ed & 0xffffull;
         unsigned long long val;
         switch (sub) {
-        case 0: val = ea - bias; break;                                      // sum qx (two's complement)
-        case 1: val = eb - bias; break;
-        case 2: val = (ec & ((1ull << 40) - 1)) - bias; break;
+        case 0: val = ea; break;                                             // sum qx
+        case 1: val = eb; break;
+        case 2: val = ec & ((1ull << 40) - 1); break;
         case 3: val = (cnt << 32) | ((ed >> 16) & 0xffffffull); break;      // count << 32 | sum r
         case 4: val = ((ed >> 40) << 32) | (ec >> 40); break;               // sum g << 32 | sum b
         case 5:   // tile bits 0-3 as 16-bit contribution counters
@@ -1077,6 +1097,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
     }
 }
+
+#include "voxel_k1_fast.inc"
 
 // ---------------------------------------------------------------------------
 // K2: octree bounding-box replay / global grid box
@@ -1367,11 +1389,11 @@ __global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWor
         for (int a = 0; a < 3; a++) vox[a] = (double)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2);
         const unsigned long long cr = w23.y, gb = w45.x;
         const uint32_t cnt = (uint32_t)(cr >> 32);
-        const double n = (double)cnt, unit = (double)P.fix_scale;
-        // mean = voxel origin + mean offset; one rounding to fp32 at the end
-        ox[r] = (float)(vox[0] * P.leaf_d + ((double)(long long)w01.x / n) / unit);
-        oy[r] = (float)(vox[1] * P.leaf_d + ((double)(long long)w01.y / n) / unit);
-        oz[r] = (float)(vox[2] * P.leaf_d + ((double)(long long)w23.x / n) / unit);
+        const double scale = P.q_unit / (double)cnt;
+        // mean = (voxel + mean position inside the voxel) / inv_leaf; one rounding to fp32 at the end
+        ox[r] = (float)(vox[0] * P.vox_unit + (double)(long long)w01.x * scale);
+        oy[r] = (float)(vox[1] * P.vox_unit + (double)(long long)w01.y * scale);
+        oz[r] = (float)(vox[2] * P.vox_unit + (double)(long long)w23.x * scale);
         // pcl AccumulatorRGBA: float sums (exact integers here) / n, truncated
         const float fn = (float)cnt;
         const uint32_t rr = (uint32_t)__fdiv_rn((float)(uint32_t)(cr & 0xffffffffu), fn);
@@ -1406,10 +1428,10 @@ __device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W
     const unsigned long long cr = w23.y, gb = w45.x;
     const uint32_t cnt = (uint32_t)(cr >> 32);
     // mean = voxel origin + mean offset (f64, one division), one rounding to fp32 at the end
-    const double scale = 1.0 / ((double)cnt * (double)P.fix_scale);
-    ox[r] = (float)(vox[0] * P.leaf_d + (double)(long long)w01.x * scale);
-    oy[r] = (float)(vox[1] * P.leaf_d + (double)(long long)w01.y * scale);
-    oz[r] = (float)(vox[2] * P.leaf_d + (double)(long long)w23.x * scale);
+    const double scale = P.q_unit / (double)cnt;
+    ox[r] = (float)(vox[0] * P.vox_unit + (double)(long long)w01.x * scale);
+    oy[r] = (float)(vox[1] * P.vox_unit + (double)(long long)w01.y * scale);
+    oz[r] = (float)(vox[2] * P.vox_unit + (double)(long long)w23.x * scale);
     const float fn = (float)cnt;
     const uint32_t rr = (uint32_t)__fdiv_rn((float)(uint32_t)(cr & 0xffffffffu), fn);
     const uint32_t gg = (uint32_t)__fdiv_rn((float)(uint32_t)(gb >> 32), fn);
@@ -1752,6 +1774,7 @@ struct Workspace {
     int shrink = 0;                    // log2 of how much smaller than "one workgroup per CU" the workgroups are made (sparse clouds)
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
     bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
+    bool no_fast = false;              // the fast accumulate kernel gave this kind of cloud back (ERR_FAST_PATH): use the general one
     size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
     float hint_cell = 0.f;
     bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
@@ -1767,7 +1790,7 @@ struct Workspace {
     uint32_t *bitmaps = nullptr;
     uint32_t *seg_count = nullptr;
     float *faces = nullptr;            // device copy of the threshold table
-    float faces_host[3 * FACES];       // what the device copy holds
+    uint32_t faces_host[FACE_TABLE_WORDS];   // what the device copy holds
     double faces_mn0[3] = {0, 0, 0};   //   ... and what it was computed from
     double faces_res = 0;
     bool faces_valid = false;
@@ -1883,7 +1906,7 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipMalloc((void **)&ws.bboxes, (size_t)nranges * 6 * sizeof(float)));
         ws.bbox_cap = nranges;
     }
-    if (!ws.faces) CW_HIP_TRY(hipMalloc((void **)&ws.faces, 3 * FACES * sizeof(float)));
+    if (!ws.faces) CW_HIP_TRY(hipMalloc((void **)&ws.faces, FACE_TABLE_WORDS * sizeof(uint32_t)));
     return true;
 }
 
@@ -1963,6 +1986,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         ws.shrink = 0;
         ws.calm = 0;
         ws.incoherent = false;
+        ws.no_fast = false;
     }
     ws.hint_cell = cellsize;
     ws.hint_n = n;
@@ -1980,18 +2004,21 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     P.nranges = (uint32_t)nwaves;
     P.leaf = cellsize;
     P.inv_leaf = 1.0f / cellsize;
-    P.fix_scale = FIX_ONE_F / cellsize;
-    bool wide = false;
+    P.vox_unit = 1.0 / (double)P.inv_leaf;
+    P.q_unit = P.vox_unit / 8388608.0;
     bool local_leaves = true;   // leaf ids resolved per workgroup at flush time; off after ERR_LOCAL_LEAVES
     P.leaf_d = (double)cellsize;
     const float octree_cellsize = (8 * 8) * cellsize;   // reference src/cwipc_filters.cpp:113-114
     P.res = (double)octree_cellsize;
     P.leaf_split = leaf_split ? 1 : 0;
-    static const uint32_t ablate_knob = []() { const char *e = getenv("CWIPC_VOXEL_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();   // debug knob, read once
+#ifdef CWIPC_DEBUG_KNOBS
+    static const uint32_t ablate_knob = []() { const char *e = getenv("CWIPC_VOXEL_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();   // read once
+    if (ablate_knob) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_VOXEL_ABLATE is set: results are WRONG (timing experiments only)");
     P.ablate = ablate_knob;
+#endif
 
     // ---- anchor and face thresholds (host, f64) ----
-    float faces_host[3 * FACES];
+    uint32_t faces_host[FACE_TABLE_WORDS];
     double faces_key_mn0[3] = {0, 0, 0};
     memset(faces_host, 0, sizeof(faces_host));
     if (leaf_split) {
@@ -2020,8 +2047,19 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (cached) {
             memcpy(faces_host, ws.faces_host, sizeof(faces_host));
         } else {
-            for (int a = 0; a < 3; a++)
-                for (int i = 0; i < FACES; i++) faces_host[a * FACES + i] = leaf_threshold(P.mn0[a], P.res, P.face_base[a] + i);
+            for (int a = 0; a < 3; a++) {
+                for (int i = 0; i < FACES; i++) {
+                    const float T = leaf_threshold(P.mn0[a], P.res, P.face_base[a] + i);
+                    // the voxel the face cuts (the fp32 product and floor of the kernels), and where the voxel above it begins
+                    const float g = floorf(T * P.inv_leaf);
+                    const bool sane = std::isfinite(T) && fabsf(g) < 1.0e9f;
+                    const int tf = sane ? (int)g : (T > 0 ? INT32_MAX : INT32_MIN);
+                    const float Tv = sane ? voxel_upper_bound(P.inv_leaf, tf) : T;
+                    memcpy(&faces_host[FT_T + a * FACES + i], &T, 4);
+                    memcpy(&faces_host[FT_TV + a * FACES + i], &Tv, 4);
+                    memcpy(&faces_host[FT_TF + a * FACES + i], &tf, 4);
+                }
+            }
         }
         faces_key_mn0[0] = P.mn0[0]; faces_key_mn0[1] = P.mn0[1]; faces_key_mn0[2] = P.mn0[2];
     } else {
@@ -2030,6 +2068,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
 
     uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 64;   // 64 grids = 1.3 GB; grown x4 when a cloud has more leaves
     int mode = leaf_split ? 1 : 0;
+    bool used_fast = false;
     for (int attempt = 0; attempt < 10; attempt++) {
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = ws.leaf_cap - 1;
@@ -2047,7 +2086,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ws.head_clean[blk]) ok = hipMemsetAsync(head, 0, ws.head_bytes, c.stream) == hipSuccess;
         ws.head_clean[blk] = false;
         if (ok && mode == 1 && !(ws.faces_valid && memcmp(ws.faces_host, faces_host, sizeof(faces_host)) == 0)) {
-            float *stage = (float *)c.staging(sizeof(faces_host));
+            uint32_t *stage = (uint32_t *)c.staging(sizeof(faces_host));
             ok = stage != nullptr;
             if (ok) {
                 memcpy(stage, faces_host, sizeof(faces_host));
@@ -2063,22 +2102,43 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         K1Params K;
         memset(&K, 0, sizeof(K));
         K.n = (uint32_t)n; K.per_wave = (uint32_t)P.per_wave;
-        K.inv_leaf = P.inv_leaf; K.leaf = P.leaf; K.fix_scale = P.fix_scale;
+        K.inv_leaf = P.inv_leaf;
         K.ib0 = P.ib[0]; K.ib1 = P.ib[1]; K.ib2 = P.ib[2];
         K.fb0 = P.face_base[0]; K.fb1 = P.face_base[1]; K.fb2 = P.face_base[2];
         K.leaf_mask = P.leaf_mask; K.list_cap = P.list_cap; K.ablate = P.ablate;
-        K.q_bias = wide ? Q_BIAS_WIDE : Q_BIAS;
         K.local_leaves = local_leaves ? 1u : 0u;
         K.want_list = leaf_split ? 0u : 1u;
-        K.q_round = (float)K.q_bias + 0.5f;
-        K.g_check = wide ? G_CHECK_WIDE : G_CHECK;
         K.mn0[0] = P.mn0[0]; K.mn0[1] = P.mn0[1]; K.mn0[2] = P.mn0[2];
         K.res = P.res;
-        if (mode == 0) {
-            CW_LAUNCH("voxel_accumulate", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
+        // The fast variant takes coherent clouds that fit its workgroup table and key; it says so (ERR_FAST_PATH) when a
+        // cloud does not, and the pass is run again with the general variant (which is remembered for the clouds to come).
+        static const bool fast_off = []() { const char *e = getenv("CWIPC_VOXEL_GENERAL"); return e && atoi(e) != 0; }();   // test knob: general variant only
+        const bool fast = mode != 2 && !ws.no_fast && ws.shrink == 0 && !fast_off;
+        used_fast = fast;
+        if (fast) {
+            FastParams F;
+            memset(&F, 0, sizeof(F));
+            F.n = K.n; F.per_wave = K.per_wave; F.inv_leaf = K.inv_leaf;
+            F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
+            F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
+            F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
+#ifdef CWIPC_DEBUG_KNOBS
+            static const uint32_t fast_dbg = []() { const char *e = getenv("CWIPC_FAST_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
+            if (fast_dbg) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_FAST_DBG is set: results are WRONG (timing experiments only)");
+            F.dbg = fast_dbg;
+#endif
+            if (mode == 0) {
+                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                          src.y(), src.z(), src.rgbt(), W);
+            } else {
+                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                          src.y(), src.z(), src.rgbt(), W);
+            }
+        } else if (mode == 0) {
+            CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
                       src.z(), src.rgbt(), W);
         } else if (mode == 1) {
-            CW_LAUNCH("voxel_accumulate", voxel_accumulate_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
+            CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
                       src.z(), src.rgbt(), W);
         } else {
             CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(),
@@ -2301,19 +2361,16 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (error_code) *error_code = (int)err;
         if (!ok) { hip_failed(hipGetLastError(), "voxel emit", __FILE__, __LINE__); return nullptr; }
 
-        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE | ERR_LOCAL_LEAVES | ERR_LIST_FULL;
-        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_FIXED_RANGE | ERR_LOCAL_LEAVES)) && !(err & ~retryable)) {
+        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES | ERR_LIST_FULL | ERR_FAST_PATH | (used_fast ? ERR_CELL_RANGE : 0u);
+        if (used_fast && (err & (ERR_FAST_PATH | ERR_CELL_RANGE)) && !(err & ~retryable)) {
+            // not a cloud for the fast variant (its table, its key or its slabs): the touched records were cleaned above
+            ws.no_fast = true;
+            continue;
+        }
+        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES)) && !(err & ~retryable)) {
             if (err & ERR_LOCAL_LEAVES) local_leaves = false;   // a workgroup spans more than 64 leaves: global ids in the hot loop
             // the touched records were cleaned above; change what was too small and run again
             if (err & ERR_FACE_TABLE) mode = 2;   // points beyond the threshold table: per-point f64 variant
-            if (err & ERR_FIXED_RANGE) {
-                if (wide) {
-                    cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: coordinates beyond 2^25 voxels from the origin");
-                    return nullptr;
-                }
-                wide = true;
-                P.fix_scale = FIX_ONE_WIDE_F / cellsize;
-            }
             if (err & ERR_LEAVES) {
                 if ((size_t)leaf_cap * 4 * GRID_BYTES > ((size_t)200 << 30)) {
                     cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the cloud spans more octree leaves than fit in device memory");
