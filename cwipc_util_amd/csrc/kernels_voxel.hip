@@ -2219,6 +2219,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         if (!ok) { hip_failed(launch_err != hipSuccess ? launch_err : hipGetLastError(), "voxel_accumulate", __FILE__, __LINE__); return nullptr; }
 
         uint32_t err = hw[C_ERR];
+#ifdef CWIPC_DEBUG_KNOBS
+        if (used_fast) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "debug: slab refits in this pass: " + std::to_string(hw[30]) + " (waves: " + std::to_string(nwaves) + ")");
+#endif
         {
             // adapt the workgroup size for the next call
             const uint32_t fallbacks = hw[C_FALLBACK], maxload = hw[C_MAXLOAD];
