@@ -358,7 +358,14 @@ extern "C" cwipc_pointcloud *cwipc_downsample(cwipc_pointcloud *pc, float cellsi
         return nullptr;
     }
     int err = 0;
-    auto dst = voxel_downsample(*src, cellsize, leaf_split, &err);
+    std::shared_ptr<DeferredResult> pending;
+    auto dst = voxel_downsample(src, cellsize, leaf_split, &err, leaf_split ? &pending : nullptr);
+    if (pending) {
+        // a stream of frames: the result is handed out while its kernels run (it settles when somebody asks for its points)
+        auto *rv = new cwipc_hip_pointcloud();
+        rv->adopt_deferred(pending, pc->timestamp(), cellsize);
+        return rv;
+    }
     if (!dst) return nullptr;
     return wrap(dst, pc->timestamp(), cellsize);
 }

@@ -189,6 +189,17 @@ std::shared_ptr<DeviceSoA> soa_with_new_rgbt(const std::shared_ptr<DeviceSoA> &s
 // ... and the other way round: `src`'s colour / tile words, coordinate planes of its own.
 std::shared_ptr<DeviceSoA> soa_with_new_xyz(const std::shared_ptr<DeviceSoA> &src);
 
+// A filter result that is still being computed when the call returns: its planes exist, its point count does not yet.
+// cwipc_downsample (octree path) hands these out in a stream of frames, so that the host does not stand between one
+// frame's kernels and the next one's; the first accessor that needs the points settles it (waits, and runs the pass
+// again the slow way in the rare case that its assumptions did not hold).
+struct DeferredResult {
+    virtual ~DeferredResult() {}
+    // Blocks until the result is there; nullptr = the filter failed (logged).  May be called from any thread, any
+    // number of times.
+    virtual std::shared_ptr<DeviceSoA> settle() = 0;
+};
+
 // Host memory for point buffers: page-locked and pooled when a GPU is there (the DMA engines then
 // read and write it directly, no staging copy), plain malloc otherwise.
 void *host_alloc(size_t bytes, bool *pinned);
@@ -228,18 +239,21 @@ public:
     // construction helpers
     int from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp);
     void adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize);
+    void adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize);
 
     // residency
     std::shared_ptr<DeviceSoA> device_points();   // uploads if needed; nullptr on failure
     std::shared_ptr<HostAoS> host_points();       // downloads if needed; nullptr on failure
-    bool has_device() const { return (bool)m_dev; }
-    bool has_host() const { return (bool)m_host; }
+    bool has_device() { settle(); return (bool)m_dev; }
+    bool has_host() { settle(); return (bool)m_host; }
     bool drop_host();
-    size_t npoints() const { return m_npoints; }
+    size_t npoints() { settle(); return m_npoints; }
     bool has_data() const { return m_has_data; }
 
 private:
     int copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact, bool dst_pinned = false);
+    void settle();                // a deferred result becomes an ordinary device cloud (no-op otherwise)
+    std::shared_ptr<DeferredResult> m_pending;
     std::mutex m_lock;
     uint64_t m_timestamp = 0;
     float m_cellsize = 0;
@@ -312,7 +326,10 @@ void join_copy(const JoinPart &part, const DeviceSoA &dst, hipStream_t s);
 
 // Voxel-grid downsample (kernels_voxel.hip).  Returns the new cloud's planes or
 // nullptr (error already logged).  leaf_split = positive-cellsize path.
-std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize, bool leaf_split, int *error_code);
+// With `deferred` (octree path only) the call may come back before its kernels are done: it then returns nullptr and
+// leaves the pending result in *deferred.
+std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &src, float cellsize, bool leaf_split, int *error_code,
+                                            std::shared_ptr<DeferredResult> *deferred = nullptr);
 
 // Statistical outlier removal (kernels_sor.hip).  Computes d_i into dev_dist
 // (n floats, device), returns false on failure.

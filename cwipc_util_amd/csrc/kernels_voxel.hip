@@ -1759,6 +1759,24 @@ __global__ void __launch_bounds__(RANK_THREADS) clean_by_bitmap_kernel(VoxWork W
 // ---------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------
+// An octree pass whose call has returned (DeferredResult): accumulate, replay and finalize kernels are in flight, the
+// finalize kernel writes into `spec_dst`, sized from the passes before.  Whoever needs the outcome polls the workspace's
+// pinned words for this pass's sequence number.  If the pass did not go through (an error word, more outputs than
+// spec_dst holds) the result is computed again by an ordinary, waiting call, and the workspace's next user cleans up.
+struct PendingVoxel : DeferredResult {
+    std::recursive_mutex lock;   // (settle() may run the pass again on this thread, which first asks the workspace's pending pass -- this one -- for its outcome)
+    std::shared_ptr<DeviceSoA> src, spec_dst, result;
+    volatile unsigned long long *words = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t seq = 0, spec_cap = 0;
+    float cellsize = 0;
+    bool known = false, ok = false, settled = false;
+    uint32_t err = 0, m = 0;
+    bool outcome_locked();                       // waits for the replay kernel's report; true: spec_dst holds the result
+    bool outcome() { std::lock_guard<std::recursive_mutex> g(lock); return outcome_locked(); }
+    std::shared_ptr<DeviceSoA> settle() override;
+};
+
 struct Workspace {
     int device = -1;
     int cus = 0, cus_device = -1;   // compute units of the device the workspace was last used on
@@ -1775,6 +1793,9 @@ struct Workspace {
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
     bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
     bool no_fast = false;              // the fast accumulate kernel gave this kind of cloud back (ERR_FAST_PATH): use the general one
+    int streak = 0;                    // octree passes of this kind in a row that went through without a retry
+    uint32_t *host_words = nullptr;    // page-locked: the replay kernel publishes the pass's control words here (64-bit, tagged with seq)
+    std::shared_ptr<struct PendingVoxel> pending;   // the pass still in flight on this workspace, if the call that started it has returned
     size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
     float hint_cell = 0.f;
     bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
@@ -1806,6 +1827,8 @@ struct Workspace {
         gbits = gprefix = gblock = nullptr; gwords_cap = 0;
         if (bboxes) (void)hipFree(bboxes);
         if (faces) (void)hipFree(faces);
+        if (host_words) (void)hipHostFree(host_words);
+        host_words = nullptr;
         if (bitmaps) (void)hipFree(bitmaps);
         bitmaps = nullptr; seg_count = nullptr; head = nullptr; head_bytes = 0;
         leaf_keys = nullptr; records = nullptr; occupied = nullptr; order = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
@@ -1873,6 +1896,9 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int lds_fast = (int)sizeof(FastTable);
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
         ws.device = dev;
     }
     if (ws.leaf_cap < leaf_cap) {
@@ -1907,6 +1933,10 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         ws.bbox_cap = nranges;
     }
     if (!ws.faces) CW_HIP_TRY(hipMalloc((void **)&ws.faces, FACE_TABLE_WORDS * sizeof(uint32_t)));
+    if (!ws.host_words) {
+        CW_HIP_TRY(hipHostMalloc((void **)&ws.host_words, 2 * C_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        memset(ws.host_words, 0, 2 * C_WORDS * sizeof(uint32_t));
+    }
     return true;
 }
 
@@ -1949,9 +1979,63 @@ bool fetch_first_point(const DeviceSoA &src, ThreadCtx &c) {
     return true;
 }
 
+bool PendingVoxel::outcome_locked() {
+    if (known) return ok;
+    uint32_t hw[C_SEQ];
+    const auto take = [&]() {   // true when every word carries this pass's tag
+        for (int i = 0; i < C_SEQ; i++) {
+            const unsigned long long w = words[i];
+            if ((uint32_t)(w >> 32) != seq) return false;
+            hw[i] = (uint32_t)w;
+        }
+        return true;
+    };
+    bool seen = false;
+    const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(poll_budget_us());
+    for (int spin = 0;; spin++) {
+        if ((uint32_t)(words[C_COUNT] >> 32) == seq && take()) { seen = true; break; }
+        if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) break;
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        if (hipStreamSynchronize(stream) != hipSuccess) (void)hipGetLastError();
+        seen = take();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    known = true;
+    err = seen ? hw[C_ERR] : 0x80000000u;
+    m = seen ? hw[C_COUNT] : 0u;
+    ok = seen && err == 0u && m <= spec_cap;
+    return ok;
+}
+
+std::shared_ptr<DeviceSoA> PendingVoxel::settle() {
+    std::lock_guard<std::recursive_mutex> g(lock);
+    if (settled) return result;
+    if (outcome_locked()) {
+        if (m == 0) {
+            result = soa_alloc(0);   // only points that do not count: no leaves, an empty cloud
+        } else {
+            spec_dst->npoints = m;   // the finalize kernel is filling (or has filled) the first m slots; the planes carry its `ready` event
+            result = spec_dst;
+        }
+    } else {
+        // not a pass that could be handed out early after all: once more, the waiting way (the dirty records of the
+        // failed pass are cleaned by the next user of its workspace)
+        int code = 0;
+        result = voxel_downsample(src, cellsize, true, &code, nullptr);
+    }
+    spec_dst.reset();
+    src.reset();
+    settled = true;
+    return result;
+}
+
 }  // namespace
 
-std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize, bool leaf_split, int *error_code) {
+std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &src_ptr, float cellsize, bool leaf_split, int *error_code,
+                                            std::shared_ptr<DeferredResult> *deferred) {
+    const DeviceSoA &src = *src_ptr;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     const size_t n = src.npoints;
@@ -1959,6 +2043,22 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
     t_ws_next ^= 1;
     Workspace &ws = t_ws.get(which);
     StreamOfWorkspace on_its_stream(c, which);
+    if (ws.pending) {
+        // the pass before last of this thread was handed out while it ran: its report is in by now (its words are about to
+        // be reused); if it did not go through, its records are still dirty
+        const std::shared_ptr<PendingVoxel> p = ws.pending;
+        ws.pending.reset();
+        if (p->outcome()) {
+            ws.last_m = p->m;
+        } else {
+            ws.last_m = 0;
+            ws.streak = 0;
+            if (p->err & (ERR_FAST_PATH | ERR_CELL_RANGE)) ws.no_fast = true;
+            VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count};
+            CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
+            if (!c.sync()) { hip_failed(hipGetLastError(), "voxel workspace clean-up", __FILE__, __LINE__); return nullptr; }
+        }
+    }
     src.wait_on(c.stream);   // (the caller ordered the thread's first stream behind the input's producer; this may be the second)
     if (n >= ((size_t)1 << 31)) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: more than 2^31 points");
@@ -1987,6 +2087,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         ws.calm = 0;
         ws.incoherent = false;
         ws.no_fast = false;
+        ws.streak = 0;
     }
     ws.hint_cell = cellsize;
     ws.hint_n = n;
@@ -2074,7 +2175,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         P.leaf_mask = ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
         const uint32_t seq = ++ws.seq ? ws.seq : ++ws.seq;
-        for (int i = 0; i < C_SEQ; i++) c.host_words[2 * i + 1] = 0;   // the tags of the words the replay kernel will publish
+        for (int i = 0; i < C_SEQ; i++) ws.host_words[2 * i + 1] = 0;   // the tags of the words the replay kernel will publish
         // control words, leaf table, slice counts: this pass's block (zeroed by the previous pass's replay kernel)
         const int blk = ws.parity;
         char *head = (char *)ws.head + (size_t)blk * ws.head_bytes, *next_head = (char *)ws.head + (size_t)(1 - blk) * ws.head_bytes;
@@ -2145,7 +2246,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                       src.y(), src.z(), src.rgbt(), W);
         }
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
-                  ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), c.host_words, seq);
+                  ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), ws.host_words, seq);
         const hipError_t launch_err = hipGetLastError();
         ok = launch_err == hipSuccess;
         ws.head_clean[1 - blk] = ok;
@@ -2165,6 +2266,25 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
                 // between the end of that wait and the next call's first launch is time the GPU stands still
                 spec_dst->mark_pending(c.stream);
             }
+        }
+        // A stream of frames (the two passes before went through at the first attempt): the call returns here, with its
+        // three kernels in flight.  The host does not wait for the count any more, so the next call's accumulate kernel
+        // is queued while this pass's replay and finalize kernels still run (on the thread's other stream), and the
+        // 15 us that lay between two accumulate kernels (replay kernel + the host's return, next entry and launch) are gone.
+        static const bool defer_on = []() { const char *e = getenv("CWIPC_DEFER"); return !e || atoi(e) != 0; }();
+        if (deferred && defer_on && leaf_split && attempt == 0 && ok && spec_dst && ws.streak >= 2) {
+            auto p = std::make_shared<PendingVoxel>();
+            p->src = src_ptr;
+            p->spec_dst = spec_dst;
+            p->words = reinterpret_cast<volatile unsigned long long *>(ws.host_words);
+            p->stream = c.stream;
+            p->seq = seq;
+            p->spec_cap = spec_cap;
+            p->cellsize = cellsize;
+            src.note_reader(c.stream);   // the input's planes are not recycled before the accumulate kernel is done with them
+            ws.pending = p;
+            *deferred = p;
+            return nullptr;
         }
         // Plain grid: the same, five small kernels instead of one (mark, block counts, block scan, emit, unmark), with
         // room for last call's count (+25 %) and the index bitmap as it stands; each of them checks on the device
@@ -2192,7 +2312,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
         // polling at most, then the ordinary stream wait, which also reports launch failures)
         uint32_t hw[C_SEQ];   // the published control words
         {
-            volatile unsigned long long *words = reinterpret_cast<volatile unsigned long long *>(c.host_words);
+            volatile unsigned long long *words = reinterpret_cast<volatile unsigned long long *>(ws.host_words);
             const auto take = [&]() {   // true when every word carries this pass's tag
                 for (int i = 0; i < C_SEQ; i++) {
                     const unsigned long long w = words[i];
@@ -2402,6 +2522,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const DeviceSoA &src, float cellsize
             }
             return soa_alloc(0);
         }
+        if (leaf_split) ws.streak = attempt == 0 ? ws.streak + 1 : 0;
         return dst;
     }
     cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: could not size the workspace");

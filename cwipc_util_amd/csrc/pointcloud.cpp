@@ -106,6 +106,7 @@ cwipc_hip_pointcloud::~cwipc_hip_pointcloud() { free(); }
 // reference :149-163, :356-366 -- idempotent, releases data and metadata, keeps the shell object.
 void cwipc_hip_pointcloud::free() {
     std::lock_guard<std::mutex> lock(m_lock);
+    m_pending.reset();   // (a pass still in flight looks after its input, its output and its workspace itself)
     if (m_has_data) {
         count_dealloc();
         m_has_data = false;
@@ -119,6 +120,7 @@ void cwipc_hip_pointcloud::free() {
 
 // reference :114-118, :323-327 -- shares the point data, counts as one more allocation, metadata not copied.
 cwipc_pointcloud *cwipc_hip_pointcloud::_shallowcopy() {
+    settle();
     std::lock_guard<std::mutex> lock(m_lock);
     auto *rv = new cwipc_hip_pointcloud();
     rv->m_timestamp = m_timestamp;
@@ -142,6 +144,7 @@ void cwipc_hip_pointcloud::_set_timestamp(uint64_t timestamp) { m_timestamp = ti
 // distance between every point and the FIRST point (prevPoint never advances).
 // Rare and O(N): done on the host copy.
 void cwipc_hip_pointcloud::_set_cellsize(float cellsize) {
+    if (cellsize < 0) settle();
     if (cellsize < 0 && m_has_data) {
         auto host = host_points();
         float minDistance = std::numeric_limits<float>::infinity();
@@ -163,6 +166,7 @@ void cwipc_hip_pointcloud::_set_cellsize(float cellsize) {
 }
 
 int cwipc_hip_pointcloud::count() {
+    settle();
     if (!m_has_data) {
         cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_util", "count: NULL pointcloud");
         return 0;
@@ -171,6 +175,7 @@ int cwipc_hip_pointcloud::count() {
 }
 
 size_t cwipc_hip_pointcloud::get_uncompressed_size() {
+    settle();
     if (!m_has_data) {
         cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_util", "get_uncompressed_size: NULL pointcloud");
         return 0;
@@ -184,6 +189,7 @@ int cwipc_hip_pointcloud::copy_uncompressed(struct cwipc_point *pointbuf, size_t
 }
 
 int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, bool exact, bool dst_pinned) {
+    settle();
     if (!m_has_data) {
         cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_util", "copy_uncompressed: NULL pointcloud");
         return 0;
@@ -302,8 +308,45 @@ void cwipc_hip_pointcloud::adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t
     }
 }
 
+void cwipc_hip_pointcloud::adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize) {
+    std::lock_guard<std::mutex> lock(m_lock);
+    m_timestamp = timestamp;
+    m_cellsize = cellsize;
+    m_npoints = 0;
+    m_dev.reset();
+    m_host.reset();
+    m_pending = pending;
+    m_exact_size = false;
+    if (!m_has_data) {
+        m_has_data = true;
+        count_alloc();
+    }
+}
+
+void cwipc_hip_pointcloud::settle() {
+    std::shared_ptr<DeferredResult> p;
+    {
+        std::lock_guard<std::mutex> lock(m_lock);
+        p = m_pending;
+    }
+    if (!p) return;
+    std::shared_ptr<DeviceSoA> r = p->settle();   // (idempotent: two threads settling at once get the same planes)
+    std::lock_guard<std::mutex> lock(m_lock);
+    if (m_pending != p) return;
+    m_pending.reset();
+    if (r) {
+        m_dev = r;
+        m_npoints = r->npoints;
+    } else {
+        // the filter failed after the call had returned (already logged): what the caller holds is an empty cloud
+        m_host = std::make_shared<HostAoS>();
+        m_npoints = 0;
+    }
+}
+
 // H2D: pinned staging -> device AoS -> de-interleave kernel -> SoA planes.
 std::shared_ptr<DeviceSoA> cwipc_hip_pointcloud::device_points() {
+    settle();
     std::lock_guard<std::mutex> lock(m_lock);
     if (m_dev && m_dev->device == current_device()) {
         if (m_dev->ready) {   // result of a call whose last kernel may still be running: order this thread's stream after it
@@ -384,6 +427,7 @@ std::shared_ptr<DeviceSoA> cwipc_hip_pointcloud::device_points() {
 }
 
 std::shared_ptr<HostAoS> cwipc_hip_pointcloud::host_points() {
+    settle();
     {
         std::lock_guard<std::mutex> lock(m_lock);
         if (m_host) return m_host;
@@ -404,6 +448,7 @@ std::shared_ptr<HostAoS> cwipc_hip_pointcloud::host_points() {
 }
 
 bool cwipc_hip_pointcloud::drop_host() {
+    settle();
     std::lock_guard<std::mutex> lock(m_lock);
     if (!m_dev) return false;
     m_host.reset();

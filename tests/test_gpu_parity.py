@@ -325,8 +325,9 @@ def test_downsample_means_are_correctly_rounded(gpu, oracle, synth):
         for f in ('x', 'y', 'z'):
             mean = np.add.reduceat(pts[f][order].astype(np.float64), start) / cnt
             err = np.abs(got[f].astype(np.float64) - mean)
-            # fixed-point resolution is leaf * 2^-23; final rounding to fp32 adds half an ulp
-            assert err.max() <= float(leaf) * 2.0 ** -22 + np.spacing(np.float32(np.abs(mean).max())), (cell, f, err.max())
+            # position inside the voxel = fract(fl(p / leaf)) to 2^-23 of a voxel: the fp32 product costs up to half an ulp of
+            # the coordinate, the final rounding to fp32 another half
+            assert err.max() <= float(leaf) * 2.0 ** -22 + 1.5 * np.spacing(np.float32(np.abs(mean).max())), (cell, f, err.max())
         assert (got['tile'] == np.bitwise_or.reduceat(pts['tile'][order], start)).all()
 
 
@@ -536,6 +537,66 @@ def test_downsample_is_reproducible(gpu, synth):
     c = gpu.cwipc_downsample(pc, 0.02).get_numpy_array()
     d = gpu.cwipc_downsample(pc, 0.01).get_numpy_array()
     assert same(a, b) and same(a, d) and len(c) < len(a)
+
+
+def test_downsample_stream_of_frames_returns_early(gpu, oracle, synth):
+    """In a stream of frames (the same kind of cloud again and again) cwipc_downsample hands its result out while its kernels
+    still run; the cloud settles when somebody asks for its points.  Every frame must be what a lone call gives, whatever
+    is asked first, however many results are pending, and also when a frame does not look like the ones before (far more
+    voxels than the result was sized for: the pass is run again behind the scenes)."""
+    import gc
+    pts, cs = synth(300000)
+    want = gpu.cwipc_downsample(make_cloud(gpu, pts, cs, 5), 0.01).get_numpy_array()
+    exp, _ = oracle.downsample(pts, cs, 0.01)
+    assert len(want) == len(exp)
+    pc = make_cloud(gpu, pts, cs, 5)
+    gpu.cwipc_hip_upload(pc, drop_host_copy=True)
+    frames = [gpu.cwipc_downsample(pc, 0.01) for _ in range(12)]          # nothing asked in between: up to two in flight
+    assert same(frames[7].get_numpy_array(), want)                          # out of order
+    assert [f.count() for f in frames] == [len(want)] * 12
+    assert same(frames[11].get_numpy_array(), want) and frames[3].timestamp() == 5
+    chained = gpu.cwipc_tilefilter(gpu.cwipc_downsample(pc, 0.01), 1)      # a pending result as the next filter's input
+    assert same(chained.get_numpy_array(), want[want['tile'] == 1])
+    for _ in range(6):                                                      # results dropped without ever being looked at
+        gpu.cwipc_downsample(pc, 0.01)
+    gc.collect()
+    assert same(gpu.cwipc_downsample(pc, 0.01).get_numpy_array(), want)
+    # the same number of points, spread over eight times the volume: the result sized from the frames before is too small
+    rng = np.random.default_rng(11)
+    wide = pts.copy()
+    wide['x'] *= 2.0; wide['y'] *= 2.0; wide['z'] *= 2.0
+    wide_exp, _ = oracle.downsample(wide, cs, 0.01)
+    assert len(wide_exp) > 2 * len(want)
+    stream = [gpu.cwipc_downsample(pc, 0.01) for _ in range(4)]
+    odd = gpu.cwipc_downsample(make_cloud(gpu, wide, cs, 6), 0.01)
+    after = [gpu.cwipc_downsample(pc, 0.01) for _ in range(4)]
+    got = odd.get_numpy_array()
+    assert len(got) == len(wide_exp) and np.abs(got['x'].astype(np.float64) - wide_exp['x']).max() <= XYZ_TOL
+    assert all(same(f.get_numpy_array(), want) for f in stream + after)
+    assert gpu.cwipc_dangling_allocations(False) >= 0
+
+
+def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
+    """The lean accumulate kernel and the general one share one quantisation: bit-identical clouds (the general one is forced
+    through CWIPC_VOXEL_GENERAL in a process of its own)."""
+    import subprocess, sys, tempfile
+    pts, cs = synth(300000, 0.3)
+    fast = {c: gpu.cwipc_downsample(make_cloud(gpu, pts, cs), c).get_numpy_array() for c in (0.01, -0.01, 0.004)}
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "pts.npy"), pts)
+        code = (
+            "import sys, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "import cwipc_util_amd as cw\n"
+            "pts = np.load(%r)\n"
+            "for c in (0.01, -0.01, 0.004):\n"
+            "    pc = cw.cwipc_from_numpy_array(pts, 1); pc._set_cellsize(%r)\n"
+            "    np.save(%r %% c, cw.cwipc_downsample(pc, c).get_numpy_array())\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(tmp, "pts.npy"), cs, os.path.join(tmp, "out_%s.npy"))
+        env = dict(os.environ, CWIPC_VOXEL_GENERAL="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        for c, got in fast.items():
+            assert same(got, np.load(os.path.join(tmp, "out_%s.npy" % c))), c
 
 
 def test_downsample_grid_overflow_is_an_error(gpu, oracle):
