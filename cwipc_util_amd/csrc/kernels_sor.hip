@@ -240,8 +240,20 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
             first[r] = last[r] = 0;
             if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) row_range(x0, x1, y, z, first[r], last[r]);
         }
+        // the query's own row first; then a row only if it can still hold one of the k + 1 nearest: its nearest edge must be
+        // closer than the worst distance kept so far (bound taken a little short: rounding never skips a row that matters)
+        const float eps = (float)(g.h * 1e-5), hf = (float)g.h;
+        const float ylo = (float)((double)g.mn[1] + (double)cy * g.h), zlo = (float)((double)g.mn[2] + (double)cz * g.h);
+        auto gap = [&](float v, float lo_face, int o) {
+            const float d = o == 0 ? 0.f : (o < 0 ? v - lo_face : lo_face + hf - v);
+            const float t = fmaxf(d - eps, 0.f);
+            return t * t;
+        };
+        for (uint32_t e = first[4]; e < last[4]; e++) candidate(sorted[e]);
 #pragma unroll
         for (int r = 0; r < 9; r++) {
+            if (r == 4) continue;
+            if (gap(q.y, ylo, r % 3 - 1) + gap(q.z, zlo, r / 3 - 1) >= best[KCAP - 1]) continue;
             for (uint32_t e = first[r]; e < last[r]; e++) candidate(sorted[e]);
         }
     }
