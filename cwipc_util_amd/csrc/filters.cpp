@@ -260,6 +260,22 @@ extern "C" int cwipc_hip_tiles_used(cwipc_pointcloud *pc, uint8_t *used256) {
     return count;
 }
 
+// reference python/cwipc/filters/simulatecams.py:44-70 (hard = True): the per-point loop; the centroid is the caller's
+extern "C" cwipc_pointcloud *cwipc_hip_simulatecams(cwipc_pointcloud *pc, int ncamera, float centroid_x, float centroid_z, const double *camera_dirs) {
+    if (pc == nullptr || camera_dirs == nullptr || ncamera < 1 || ncamera > 32) return nullptr;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    auto src = device_input("cwipc_hip_simulatecams", pc, keep);
+    if (!src) return nullptr;
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    auto dst = soa_with_new_rgbt(src);   // the coordinates do not change: the result holds the very same planes
+    if (!dst) return nullptr;
+    k::map_cameras(*src, *dst, ncamera, centroid_x, centroid_z, camera_dirs, c.stream);
+    if (!c.sync()) return nullptr;
+    inherit_first(*dst, *src);
+    return wrap(dst, pc->timestamp(), pc->cellsize());
+}
+
 // reference python/cwipc/filters/colorize.py:100-119
 extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid) {
     if (pc == nullptr || lut == nullptr || valid == nullptr) return nullptr;

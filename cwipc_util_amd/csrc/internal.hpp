@@ -238,7 +238,7 @@ public:
 
     // construction helpers
     int from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp);
-    void adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize);
+    void adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize, bool exact_size = false);
     void adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize);
 
     // residency
@@ -308,6 +308,11 @@ void map_tile(const DeviceSoA &src, const DeviceSoA &dst, const uint8_t *dev_map
 void map_color_bits(const DeviceSoA &src, const DeviceSoA &dst, uint32_t clearBits, uint32_t setBits, hipStream_t s);
 // mode 0: p' = R p + t with m = rows of [R | t]; mode 1: p' = (p + (m[3], m[7], m[11])) * m[0]; f64 arithmetic, one rounding to fp32
 void map_affine(const DeviceSoA &src, const DeviceSoA &dst, const double m[12], int mode, hipStream_t s);
+// the synthetic source's cloud written straight into device planes; the tables are device memory (see synthetic.cpp)
+void synthetic_fill(const DeviceSoA &dst, int hsteps, int asteps, float m_angle, bool eyes_white, const float *radius, const float *height,
+                    const float *angle, const double *sin_a, const double *cos_a, hipStream_t s);
+// simulatecams (hard): tile = 1 << index of the camera direction (dirs: cos, sin per camera) nearest to the centred position
+void map_cameras(const DeviceSoA &src, const DeviceSoA &dst, int ncam, float cen_x, float cen_z, const double *dirs, hipStream_t s);
 // ORs the set of tile values that occur into 8 device words
 void tiles_used(const DeviceSoA &src, uint32_t *dev_bits8, hipStream_t s);
 // colorize: dev_table = 256 entries of {double cw[3]; double valid;} followed by 256 doubles old/255.0, then (1-w).

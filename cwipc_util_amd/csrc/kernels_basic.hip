@@ -466,6 +466,95 @@ void map_affine(const DeviceSoA &src, const DeviceSoA &dst, const double m[12], 
               dst.rgbt(), n);
 }
 
+// The synthetic source's points, generated where they are going to be used (reference src/cwipc_synthetic.cpp:182-222).
+// Per point the reference takes one product per coordinate of a per-row value (the radius) and a per-column value (sin /
+// cos of the angle): those two tables come from the host, made with the host's libm exactly as the reference makes
+// them, so the coordinates and tiles are the reference's bit for bit.  The colours take a double-precision sine of a sum
+// that differs per point; that one is computed here.  An error of a unit in the last place of that sine reaches the
+// 8-bit colour only across two rounding boundaries (double -> float, then the truncation of 255 r): the test suite
+// compares whole clouds against the host generator and has not seen a differing byte.
+struct SyntheticArgs {
+    int hsteps, asteps;
+    float m_angle;
+    int eyes_white;   // fmod(m_angle, pi / 2) > 0.08 (reference :206-210), evaluated on the host
+    const float *radius, *height, *angle;   // [hsteps], [hsteps], [asteps]
+    const double *sin_a, *cos_a;            // [asteps]
+};
+
+__global__ void __launch_bounds__(BLOCK) synthetic_kernel(SyntheticArgs a, float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
+                                                         uint32_t *__restrict__ ow, size_t n) {
+    const float pi = 3.14159265358979f;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const int hi = (int)(i / (size_t)a.asteps), ai = (int)(i % (size_t)a.asteps);
+        const float height = a.height[hi], angle = a.angle[ai], radius = a.radius[hi];
+        const float x = (float)__dmul_rn((double)radius, a.sin_a[ai]);
+        const float y = (float)__dmul_rn((double)radius, a.cos_a[ai]);
+        // float r = (1 + sin((double)(2 * pi * height + m_angle + angle))) / 2;  -- the argument is a float expression
+        const float t2 = __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(2.0f, pi), height), a.m_angle), angle);
+        const float t3 = __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(3.0f, pi), height), a.m_angle), angle);
+        const float t4 = __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(4.0f, pi), height), a.m_angle), angle);
+        const float r = (float)__ddiv_rn(__dadd_rn(1.0, sin((double)t2)), 2.0);
+        const float g = (float)__ddiv_rn(__dadd_rn(1.0, sin((double)t3)), 2.0);
+        const float b = (float)__ddiv_rn(__dadd_rn(1.0, sin((double)t4)), 2.0);
+        int rr = (int)__dmul_rn((double)r, 255.0), gg = (int)__dmul_rn((double)g, 255.0), bb = (int)__dmul_rn((double)b, 255.0);
+        if (height > 1.7 && height < 1.8 &&
+            (((double)angle > (double)pi * 0.083 && (double)angle < (double)pi * 0.1667) ||
+             ((double)angle > (double)pi * 1.833 && (double)angle < (double)pi * 1.917))) {
+            if (a.eyes_white) rr = gg = bb = 255;
+        }
+        ox[i] = -x;
+        oy[i] = height;
+        oz[i] = y;
+        ow[i] = (uint32_t)(rr & 0xff) | ((uint32_t)(gg & 0xff) << 8) | ((uint32_t)(bb & 0xff) << 16) | ((y < 0 ? 1u : 2u) << 24);
+    }
+}
+
+void synthetic_fill(const DeviceSoA &dst, int hsteps, int asteps, float m_angle, bool eyes_white, const float *radius, const float *height,
+                    const float *angle, const double *sin_a, const double *cos_a, hipStream_t s) {
+    const size_t n = (size_t)hsteps * asteps;
+    if (!n) return;
+    SyntheticArgs a{hsteps, asteps, m_angle, eyes_white ? 1 : 0, radius, height, angle, sin_a, cos_a};
+    CW_LAUNCH("synthetic_fill", synthetic_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, a, dst.x(), dst.y(), dst.z(), dst.rgbt(), n);
+}
+
+// simulated cameras, hard assignment (reference python/cwipc/filters/simulatecams.py:44-70): every point gets the tile mask
+// 1 << c of the camera direction c (on a circle in the x-z plane) its centred, flattened position has the largest dot
+// product with.  The arithmetic is numpy's: position minus centroid in float32, the dot product in float64 accumulated
+// in index order the way numpy.dot (cblas_ddot on x86 with FMA) does for three terms -- fl(x cx) first, then one fused
+// multiply-add for z cz, the y terms being zero -- and of equal dot products the camera with the HIGHER index wins
+// (numpy.argsort's insertion sort is stable, and the reference takes the last of the ascending order).
+struct CameraArgs {
+    int ncam;
+    float cen_x, cen_z;
+    double dir[2 * 32];   // cos, sin per camera
+};
+
+__global__ void __launch_bounds__(BLOCK) camera_assign_kernel(CameraArgs a, const float *__restrict__ x, const float *__restrict__ z,
+                                                             const uint32_t *__restrict__ rgbt, uint32_t *__restrict__ ow, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const double vx = (double)__fsub_rn(x[i], a.cen_x), vz = (double)__fsub_rn(z[i], a.cen_z);
+        int best = 0;
+        double best_d = 0;
+        for (int c = 0; c < a.ncam; c++) {
+            const double d = fma(vz, a.dir[2 * c + 1], __dmul_rn(vx, a.dir[2 * c]));
+            if (c == 0 || d >= best_d) { best = c; best_d = d; }
+        }
+        // (the reference stores 1 << c into a float matrix column and casts it to uint8)
+        ow[i] = (rgbt[i] & 0x00ffffffu) | (((1u << best) & 0xffu) << 24);
+    }
+}
+
+void map_cameras(const DeviceSoA &src, const DeviceSoA &dst, int ncam, float cen_x, float cen_z, const double *dirs, hipStream_t s) {
+    const size_t n = src.npoints;
+    if (!n) return;
+    CameraArgs a;
+    a.ncam = ncam;
+    a.cen_x = cen_x;
+    a.cen_z = cen_z;
+    for (int i = 0; i < 2 * ncam; i++) a.dir[i] = dirs[i];
+    CW_LAUNCH("map_cameras", camera_assign_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, a, src.x(), src.z(), src.rgbt(), dst.rgbt(), n);
+}
+
 // which tile values occur: 256-bit set (8 words)
 __global__ void __launch_bounds__(BLOCK) tiles_used_kernel(const uint32_t *__restrict__ rgbt, size_t n, uint32_t *__restrict__ bits) {
     __shared__ uint32_t local[8];

@@ -1777,8 +1777,11 @@ struct PendingVoxel : DeferredResult {
     std::shared_ptr<DeviceSoA> settle() override;
 };
 
+std::atomic<size_t> g_workspace_bytes{0};   // device memory held by voxel workspaces (cwipc_hip_workspace_bytes)
+
 struct Workspace {
     int device = -1;
+    size_t grid_bytes = 0;             // what this workspace has added to g_workspace_bytes
     int cus = 0, cus_device = -1;   // compute units of the device the workspace was last used on
     uint32_t leaf_cap = 0;     // leaf hash capacity = number of grids (power of two)
     size_t list_cap = 0;
@@ -1830,6 +1833,8 @@ struct Workspace {
         if (host_words) (void)hipHostFree(host_words);
         host_words = nullptr;
         if (bitmaps) (void)hipFree(bitmaps);
+        g_workspace_bytes -= grid_bytes;
+        grid_bytes = 0;
         bitmaps = nullptr; seg_count = nullptr; head = nullptr; head_bytes = 0;
         leaf_keys = nullptr; records = nullptr; occupied = nullptr; order = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
         leaf_cap = 0; list_cap = 0; bbox_cap = 0;
@@ -1917,6 +1922,9 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipMalloc((void **)&ws.records, (size_t)leaf_cap * GRID_BYTES));
         CW_HIP_TRY(hipMemsetAsync(ws.records, 0, (size_t)leaf_cap * GRID_BYTES, s));   // once; K4 keeps it clean afterwards
         ws.leaf_cap = leaf_cap;
+        g_workspace_bytes -= ws.grid_bytes;
+        ws.grid_bytes = (size_t)leaf_cap * (GRID_BYTES + BITWORDS * sizeof(uint32_t)) + 2 * ws.head_bytes;
+        g_workspace_bytes += ws.grid_bytes;
     }
     if (ws.list_cap < n) {
         if (ws.occupied) (void)hipFree(ws.occupied);
@@ -2167,7 +2175,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         for (int a = 0; a < 3; a++) P.ib[a] = 2;   // bricks of 64 voxels aligned to the voxel lattice
     }
 
-    uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 64;   // 64 grids = 1.3 GB; grown x4 when a cloud has more leaves
+    uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 16;   // 16 grids = 0.33 GB (a person-sized cloud at 1 cm has 12 to 16 leaves); grown x4 when a cloud has more
     int mode = leaf_split ? 1 : 0;
     bool used_fast = false;
     for (int attempt = 0; attempt < 10; attempt++) {
@@ -2529,4 +2537,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     return nullptr;
 }
 
+size_t voxel_workspace_bytes() { return g_workspace_bytes.load(); }
+
 }  // namespace cwipc_amd
+
+extern "C" _CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_bytes(void) { return cwipc_amd::voxel_workspace_bytes(); }

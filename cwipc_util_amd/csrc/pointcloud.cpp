@@ -294,14 +294,14 @@ int cwipc_hip_pointcloud::from_points(const cwipc_point *points, size_t size, in
     return npoint;
 }
 
-void cwipc_hip_pointcloud::adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize) {
+void cwipc_hip_pointcloud::adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize, bool exact_size) {
     std::lock_guard<std::mutex> lock(m_lock);
     m_timestamp = timestamp;
     m_cellsize = cellsize;
     m_npoints = dev ? dev->npoints : 0;
     m_dev = dev;
     m_host.reset();
-    m_exact_size = false;
+    m_exact_size = exact_size;
     if (!m_has_data) {
         m_has_data = true;
         count_alloc();

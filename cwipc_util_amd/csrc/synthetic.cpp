@@ -1,6 +1,9 @@
 // synthetic.cpp -- the synthetic point cloud source, the input of every benchmark
-// configuration.  Restates reference src/cwipc_synthetic.cpp; it is an input
-// generator and runs on the host (it is not part of the timed filter path).
+// configuration.  Restates reference src/cwipc_synthetic.cpp.  With a GPU the points are
+// generated on the device, straight into the planes the filters read (k::synthetic_fill: the
+// per-row and per-column libm values still come from the host, made as the reference makes
+// them); without one -- or with CWIPC_SYNTHETIC_HOST=1 -- on the host, which is also the
+// pinned checker of the device generator (tests compare the two byte for byte).
 //
 // Two additions for reproducibility, both behind hooks the reference already has:
 //   - auxiliary_operation("test-setangle")      reference :169-179 (sets m_angle; the
@@ -15,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <vector>
 
 namespace {
 
@@ -30,6 +34,10 @@ class synthetic_source : public cwipc_activesource {
     cwipc_point *m_points = nullptr;
     size_t m_points_size = 0;
     bool m_started = false;
+    // device generator: per-row / per-column tables (radius, height | angle, sin, cos), one pool block, made once
+    void *m_tables = nullptr;
+    int m_tables_device = -1;
+    float m_first[3] = {0, 0, 0};   // the cloud's first point (coordinates do not depend on the angle)
 
 public:
     // reference :32-49 -- npoints 0 means 160000; the cloud is int(sqrt(n))^2 points.
@@ -44,6 +52,8 @@ public:
     void free() override {
         ::free(m_points);
         m_points = nullptr;
+        if (m_tables) pool_free(m_tables);
+        m_tables = nullptr;
     }
     bool reload_config(const char *) override {
         cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_synthetic", "reload_config() not implemented (nor needed)");
@@ -91,8 +101,11 @@ public:
         std::chrono::duration<float, std::ratio<1>> runtime = now - m_start;
         if (m_fps != 0) m_earliest_next = now + std::chrono::milliseconds(1000 / m_fps);
         if (!m_angle_fixed) m_angle = runtime.count();
-        generate_points();
-        cwipc_pointcloud *rv = cwipc_from_points(m_points, m_points_size, m_hsteps * m_asteps, timestamp, nullptr, CWIPC_API_VERSION);
+        cwipc_pointcloud *rv = generate_on_device(timestamp);
+        if (rv == nullptr) {
+            generate_points();
+            rv = cwipc_from_points(m_points, m_points_size, m_hsteps * m_asteps, timestamp, nullptr, CWIPC_API_VERSION);
+        }
         if (rv) {
             rv->_set_cellsize(2.0 / m_hsteps);
             if (is_metadata_requested("test-angle")) {
@@ -130,6 +143,60 @@ public:
     }
 
 private:
+    // The same cloud, generated on the device (nullptr: no GPU, or switched off -- the caller takes the host path).
+    cwipc_pointcloud *generate_on_device(uint64_t timestamp) {
+        static const bool host_only = []() { const char *e = getenv("CWIPC_SYNTHETIC_HOST"); return e && atoi(e) != 0; }();
+        const size_t n = (size_t)m_hsteps * m_asteps;
+        if (host_only || n == 0 || cwipc_hip_device_count() < 1 || current_device() >= cwipc_hip_device_count()) return nullptr;
+        ThreadCtx &c = tctx();
+        if (!c.ensure()) return nullptr;
+        const size_t nh = (size_t)m_hsteps, na = (size_t)m_asteps;
+        // layout: double sin[na] cos[na] | float radius[nh] height[nh] angle[na]
+        const size_t bytes = 2 * na * sizeof(double) + (2 * nh + na) * sizeof(float);
+        if (m_tables == nullptr || m_tables_device != current_device()) {
+            if (m_tables) pool_free(m_tables);
+            m_tables = pool_alloc(bytes);
+            if (!m_tables) return nullptr;
+            char *h = (char *)c.staging(bytes);
+            if (!h) return nullptr;
+            double *sin_a = (double *)h, *cos_a = sin_a + na;
+            float *radius = (float *)(cos_a + na), *height = radius + nh, *angle = height + nh;
+            // reference :183-196, the values that do not depend on the other loop index
+            const float pi = 3.14159265358979f;
+            const float max_height = 2.0;
+            const float delta_h = max_height / m_hsteps;
+            const float delta_a = 2 * pi / m_asteps;
+            for (int hi = 0; hi < m_hsteps; hi++) {
+                height[hi] = hi * delta_h;
+                radius[hi] = 0.3 * pow(cos((double)(height[hi] * pi / 3 - pi / 6)), 0.71);
+            }
+            for (int ai = 0; ai < m_asteps; ai++) {
+                angle[ai] = ai * delta_a;
+                sin_a[ai] = sin((double)angle[ai]);
+                cos_a[ai] = cos((double)angle[ai]);
+            }
+            const float x0 = radius[0] * sin_a[0], y0 = radius[0] * cos_a[0];
+            m_first[0] = -x0; m_first[1] = height[0]; m_first[2] = y0;
+            bool ok = hipMemcpyAsync(m_tables, h, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess;
+            ok = c.sync() && ok;
+            if (!ok) { pool_free(m_tables); m_tables = nullptr; return nullptr; }
+            m_tables_device = current_device();
+        }
+        auto dst = soa_alloc(n);
+        if (!dst) return nullptr;
+        const double *sin_a = (const double *)m_tables, *cos_a = sin_a + na;
+        const float *radius = (const float *)(cos_a + na), *height = radius + nh, *angle = height + nh;
+        const float pi = 3.14159265358979f;
+        const bool eyes_white = fmod((double)m_angle, (double)(pi / 2)) > 0.08;   // reference :209
+        k::synthetic_fill(*dst, m_hsteps, m_asteps, m_angle, eyes_white, radius, height, angle, sin_a, cos_a, c.stream);
+        if (!c.sync()) return nullptr;
+        dst->first[0] = m_first[0]; dst->first[1] = m_first[1]; dst->first[2] = m_first[2];
+        dst->has_first = true;
+        auto *rv = new cwipc_hip_pointcloud();
+        rv->adopt_device(dst, timestamp, 0.0f, /* exact_size */ true);   // (cwipc_from_points clouds want their exact size in copy_uncompressed)
+        return rv;
+    }
+
     // reference :182-222.  Mixed float/double arithmetic exactly as written there
     // (float locals, double libm calls and literals).
     void generate_points() {

@@ -1,7 +1,7 @@
 """Filter plugins of the hot path (reference python/cwipc/filters/__init__.py:19-48).
 
 Only the filters on the MI355X path exist here: voxelize, remove_outliers, crop,
-colorize (plus passthrough).  The factory accepts the reference's FILTERDESC
+colorize, transform, simulatecams (plus passthrough).  The factory accepts the reference's FILTERDESC
 syntax -- "name" or "name(args)" -- but parses the arguments with
 ast.literal_eval instead of eval.
 """
@@ -9,9 +9,9 @@ import ast
 from typing import cast
 
 from .abstract import cwipc_abstract_filter
-from . import passthrough, voxelize, crop, remove_outliers, colorize, transform
+from . import passthrough, voxelize, crop, remove_outliers, colorize, transform, simulatecams
 
-all_filters = [passthrough, voxelize, crop, remove_outliers, colorize, transform]
+all_filters = [passthrough, voxelize, crop, remove_outliers, colorize, transform, simulatecams]
 _by_name = {m.CustomFilter.filtername: m for m in all_filters}
 
 

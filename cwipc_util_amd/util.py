@@ -41,7 +41,7 @@ __all__ = [
     # MI355X extensions (no reference counterpart)
     'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked',
     'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_from_device_slots', 'cwipc_hip_copy_device_aos',
-    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used',
+    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_hip_simulatecams',
 ]
 
 # reference util.py:86, 346, 348
@@ -208,11 +208,13 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_copy_device_aos_on_stream': ([cwipc_pointcloud_p, _c.c_void_p, _c.c_size_t, _c.c_void_p], _c.c_long),
     'cwipc_hip_colorize': ([cwipc_pointcloud_p, _c.c_double, _c.c_void_p, _c.c_void_p], cwipc_pointcloud_p),
     'cwipc_hip_join_multi': ([_c.POINTER(cwipc_pointcloud_p), _c.c_int], cwipc_pointcloud_p),
+    'cwipc_hip_simulatecams': ([cwipc_pointcloud_p, _c.c_int, _c.c_float, _c.c_float, _c.c_void_p], cwipc_pointcloud_p),
     'cwipc_hip_tilefilter_masked': ([cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_transform': ([cwipc_pointcloud_p, _c.POINTER(_c.c_double)], cwipc_pointcloud_p),
     'cwipc_hip_offset_scale': ([cwipc_pointcloud_p, _c.c_double, _c.c_double, _c.c_double, _c.c_double], cwipc_pointcloud_p),
     'cwipc_hip_tiles_used': ([cwipc_pointcloud_p, _c.POINTER(_c.c_ubyte)], _c.c_int),
     'cwipc_hip_knn_mean_dist': ([cwipc_pointcloud_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_double), _c.c_float], _c.c_int),
+    'cwipc_hip_workspace_bytes': ([], _c.c_size_t),
     'cwipc_hip_profile_enable': ([_c.c_int], None),
     'cwipc_hip_profile_reset': ([], None),
     'cwipc_hip_profile_count': ([], _c.c_int),
@@ -826,6 +828,14 @@ def cwipc_hip_colorize(pc: cwipc_pointcloud_wrapper, weight: float, lut: numpy.n
     valid = numpy.ascontiguousarray(valid, dtype=numpy.uint8).reshape(256)
     rv = cwipc_util_dll_load().cwipc_hip_colorize(pc.as_cwipc_p(), float(weight), lut.ctypes.data, valid.ctypes.data)
     return _wrap_filter_result('cwipc_hip_colorize', rv)
+
+
+def cwipc_hip_simulatecams(pc: cwipc_pointcloud_wrapper, camera_vectors: numpy.ndarray, centroid: numpy.ndarray) -> cwipc_pointcloud_wrapper:
+    """Hard camera assignment of SimulatecamsFilter on the GPU: camera_vectors (ncam, 3) float64 with y = 0, centroid (3,) float32."""
+    cams = numpy.ascontiguousarray(numpy.asarray(camera_vectors, dtype=numpy.float64)[:, [0, 2]])
+    rv = cwipc_util_dll_load().cwipc_hip_simulatecams(pc.as_cwipc_p(), int(cams.shape[0]), float(numpy.float32(centroid[0])), float(numpy.float32(centroid[2])),
+                                                      cams.ctypes.data)
+    return _wrap_filter_result("cwipc_hip_simulatecams", rv)
 
 
 def cwipc_tilefilter_masked(pc: cwipc_pointcloud_wrapper, mask: int) -> cwipc_pointcloud_wrapper:

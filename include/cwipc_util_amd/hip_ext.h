@@ -24,6 +24,7 @@ _CWIPC_UTIL_EXPORT int cwipc_hip_get_device(void);
 _CWIPC_UTIL_EXPORT const char *cwipc_hip_last_error(void);    /* thread-local text of the last HIP failure ("" if none) */
 _CWIPC_UTIL_EXPORT void cwipc_hip_synchronize(void);          /* wait for the calling thread's stream */
 _CWIPC_UTIL_EXPORT size_t cwipc_hip_pool_bytes(void);         /* bytes currently held by the device memory pool */
+_CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_bytes(void);    /* device bytes held by the voxel filter's workspaces (leaf grids; two per thread that downsamples) */
 _CWIPC_UTIL_EXPORT void cwipc_hip_pool_trim(void);            /* return cached device memory to the driver */
 
 /* ---- residency ----
@@ -53,6 +54,10 @@ _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_slots_on_stream(const
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid);
+/* SimulatecamsFilter, hard assignment (reference python/cwipc/filters/simulatecams.py:44-70): tile = 1 << c for the camera direction
+ * (camera_dirs: cos, sin of 2 pi c / ncamera, as doubles) with the largest dot product with the point's position minus the
+ * centroid, y ignored.  The centroid (numpy.mean of the float32 coordinates) is computed by the caller, as the reference does. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_simulatecams(cwipc_pointcloud *pc, int ncamera, float centroid_x, float centroid_z, const double *camera_dirs);
 /* cwipc_join_multi (reference python/cwipc/util.py:1330-1332): same result as the left fold of cwipc_join, one pass. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int npc);
 /* p' = R p + t for a row-major 4x4 matrix (last row ignored), in f64, stored as float: what the reference's

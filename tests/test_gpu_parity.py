@@ -215,6 +215,56 @@ def test_transform_filter_offset_scale(gpu, oracle, synth):
     assert same(gpu.cwipc_offset_scale(make_cloud(gpu, pts[:0], cs), 1, 2, 3, 4).get_numpy_array(), pts[:0])
 
 
+@pytest.mark.parametrize("npoints,angle", [(0, 0.0), (100000, 0.7), (1000000, 2.5), (300000, 1.6), (10000000, 0.0)])
+def test_synthetic_source_on_the_device(gpu, oracle, npoints, angle):
+    """With a GPU the synthetic source writes its cloud straight into device planes (csrc/synthetic.cpp); the host generator
+    (the oracle restates it, reference src/cwipc_synthetic.cpp:182-222) is its checker: every byte equal, the white patch
+    ("eyes", :206-210) included -- angle 1.6 has fmod(angle, pi/2) < 0.08, the others not."""
+    import struct
+    src = gpu.cwipc_synthetic(0, npoints)
+    src.start()
+    out = bytearray(4)
+    assert src.auxiliary_operation("amd-fixangle", struct.pack("f", angle), out)
+    pc = src.get()
+    src.stop()
+    assert gpu.util.cwipc_util_dll_load().cwipc_hip_is_device_resident(pc.as_cwipc_p()) == 1
+    want, cs = oracle.synthetic(npoints, angle)
+    got = pc.get_numpy_array()
+    assert pc.count() == len(want) and pc.cellsize() == pytest.approx(cs, rel=0, abs=0)
+    differing = int((got.view(np.uint8).reshape(-1, 16) != want.view(np.uint8).reshape(-1, 16)).any(axis=1).sum())
+    assert differing == 0, differing
+    # and the cloud behaves like any other: the downsample anchors its octree at the first point without fetching it
+    if npoints and npoints <= 1000000:
+        if npoints <= 300000:
+            check_downsample(gpu, oracle, want, cs, 0.01)
+        assert same(gpu.cwipc_downsample(pc, 0.01).get_numpy_array(), gpu.cwipc_downsample(make_cloud(gpu, want, cs), 0.01).get_numpy_array())
+
+
+def test_simulatecams_golden(gpu):
+    """SimulatecamsFilter(hard=True) against vectors produced by the reference's own filter (tests/golden/make_simulatecams_vectors.py):
+    the tile of every point bit for bit, everything else untouched."""
+    from cwipc_util_amd.filters import factory
+    data = np.load(os.path.join(GOLDEN, "simulatecams_vectors.npz"))
+    for name in ("blob4", "blob8", "ring3", "ring8", "symmetric6"):
+        m, ncam, want = data[name + "_in"], int(data[name + "_ncam"]), data[name + "_tile"]
+        pc = gpu.cwipc_from_numpy_matrix(m, 77)
+        pc._set_cellsize(0.125)
+        out = factory("simulatecams(%d, True)" % ncam).filter(pc)
+        got = out.get_numpy_array()
+        assert (got['tile'] == want).all(), (name, int((got['tile'] != want).sum()))
+        src = pc.get_numpy_array()
+        for f in ('x', 'y', 'z', 'r', 'g', 'b'):
+            assert (got[f] == src[f]).all(), (name, f)
+        assert out.timestamp() == 77 and out.cellsize() == 0.125
+        assert gpu.util.cwipc_util_dll_load().cwipc_hip_is_device_resident(out.as_cwipc_p()) == 1
+    # the soft rule draws random numbers: every point goes to its best or second-best camera
+    m, ncam = data["ring8_in"], 8
+    soft = factory("simulatecams(8, False, 2.0)").filter(gpu.cwipc_from_numpy_matrix(m, 1)).get_numpy_array()
+    hard = data["ring8_tile"]
+    assert set(np.unique(soft['tile'])) <= {1 << c for c in range(8)}
+    assert (soft['tile'] == hard).mean() > 0.5
+
+
 def test_tiles_used(gpu, oracle, synth):
     pts, cs = synth(100000)
     assert gpu.get_tiles_used(make_cloud(gpu, pts, cs)) == oracle.tiles_used(pts) == [1, 2]
