@@ -28,6 +28,7 @@ SOURCES = [
     "pointcloud.cpp",
     "synthetic.cpp",
     "stubs.cpp",
+    "ply.cpp",
     "filters.cpp",
     "kernels_basic.hip",
     "kernels_voxel.hip",

@@ -237,7 +237,7 @@ public:
     cwipc_metadata *access_metadata() override;
 
     // construction helpers
-    int from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp);
+    int from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp, bool exact_size = true);
     void adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize, bool exact_size = false);
     void adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize);
 

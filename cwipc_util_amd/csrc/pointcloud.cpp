@@ -268,7 +268,7 @@ cwipc_metadata *cwipc_hip_pointcloud::access_metadata() {
 }
 
 // reference :329-354 -- validates npoint*16 == size, owns a copy.
-int cwipc_hip_pointcloud::from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp) {
+int cwipc_hip_pointcloud::from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp, bool exact_size) {
     if (npoint < 0 || (size_t)npoint * sizeof(cwipc_point) != size) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "from_points: size and npoint inconsistent");
         return -1;
@@ -286,7 +286,7 @@ int cwipc_hip_pointcloud::from_points(const cwipc_point *points, size_t size, in
     m_npoints = (size_t)npoint;
     m_host = host;
     m_dev.reset();
-    m_exact_size = true;
+    m_exact_size = exact_size;   // (the reference's from_points clouds insist on their exact size in copy_uncompressed, its PCL-backed ones take any buffer that is large enough)
     if (!m_has_data) {
         m_has_data = true;
         count_alloc();

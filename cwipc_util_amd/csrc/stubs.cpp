@@ -22,25 +22,6 @@ static void fail(const char *who, const char *why, char **errorMessage) {
     cwipc_log_set_errorbuf(nullptr);
 }
 
-extern "C" cwipc_pointcloud *cwipc_read(const char *filename, uint64_t, char **errorMessage, uint64_t apiVersion) {
-    if (api_version_rejected("cwipc_read", apiVersion, errorMessage)) return nullptr;
-    fail("cwipc_read", (std::string("Loading of PLY file failed: ") + (filename ? filename : "(null)") +
-                        " (PLY I/O is not part of the MI355X filter-path build; use cwipc_read_debugdump)").c_str(), errorMessage);
-    return nullptr;
-}
-
-extern "C" int cwipc_write(const char *filename, cwipc_pointcloud *, char **errorMessage) {
-    fail("cwipc_write", (std::string("Saving of PLY file failed: ") + (filename ? filename : "(null)") +
-                         " (PLY I/O is not part of the MI355X filter-path build; use cwipc_write_debugdump)").c_str(), errorMessage);
-    return -1;
-}
-
-extern "C" int cwipc_write_ext(const char *filename, cwipc_pointcloud *, int, char **errorMessage) {
-    fail("cwipc_write_ext", (std::string("Saving of PLY file failed: ") + (filename ? filename : "(null)") +
-                             " (PLY I/O is not part of the MI355X filter-path build; use cwipc_write_debugdump)").c_str(), errorMessage);
-    return -1;
-}
-
 // ---------------------------------------------------------------------------
 // capturer registry (reference src/cwipc_capturer.cpp:23-160)
 // ---------------------------------------------------------------------------

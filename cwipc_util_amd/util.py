@@ -605,7 +605,7 @@ def cwipc_dangling_allocations(log: bool) -> int:
 
 
 def cwipc_read(filename: str, timestamp: int) -> cwipc_pointcloud_wrapper:
-    """PLY reading is out of scope for the MI355X build: always raises CwipcError with the library's message."""
+    """Point cloud from a PLY file (ascii or binary; reference python/cwipc/util.py cwipc_read)."""
     errorString = ctypes.c_char_p()
     rv = cwipc_util_dll_load().cwipc_read(filename.encode('utf8'), timestamp, ctypes.byref(errorString), CWIPC_API_VERSION)
     _raise_or_warn(errorString, rv)

@@ -116,12 +116,78 @@ def test_free_is_idempotent(cwipc):
     assert dll.cwipc_pointcloud_count(p.as_cwipc_p()) == 0
 
 
-def test_read_write_ply_fail_loudly(cwipc, tmp_path):
+def test_ply_write_and_read_back(cwipc, oracle, tmp_path):
+    """cwipc_write / cwipc_write_ext / cwipc_read (reference src/cwipc_util.cpp:432-497; its tests python/test_cwipc_util.py:230-252):
+    ascii and binary, what was written comes back; ascii keeps 8 significant digits as PCL's writer does."""
+    pc, _ = _build_pointcloud(cwipc)
+    for flags in (0, cwipc.CWIPC_FLAGS_BINARY):
+        fn = str(tmp_path / ("simple%d.ply" % flags))
+        assert cwipc.cwipc_write(fn, pc, flags) == 0
+        back = cwipc.cwipc_read(fn, 4321)
+        assert back.timestamp() == 4321 and back.cellsize() == 0
+        assert list(pc.get_points()) == list(back.get_points())
+    pts, cs = oracle.synthetic(5000, 0.3)
+    pts['tile'] = np.arange(len(pts)) % 7
+    big = make_cloud(cwipc, pts, cs, 9)
+    fn = str(tmp_path / "synthetic_binary.ply")
+    assert cwipc.cwipc_write(fn, big, cwipc.CWIPC_FLAGS_BINARY) == 0
+    assert cwipc.cwipc_read(fn, 9).get_numpy_array().tobytes() == pts.tobytes()          # binary: exact
+    head = open(fn, "rb").read(400).decode("latin1")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\ncomment PCL generated\nelement vertex %d\nproperty float x\n" % len(pts))
+    assert "property uchar alpha\nelement camera 1\nproperty float view_px" in head
+    fn = str(tmp_path / "synthetic_ascii.ply")
+    assert cwipc.cwipc_write(fn, big) == 0
+    got = cwipc.cwipc_read(fn, 9).get_numpy_array()
+    for f in ('x', 'y', 'z'):
+        want = np.array([np.float32(float("%.8g" % v)) for v in pts[f]], dtype=np.float32)
+        assert (got[f] == want).all(), f
+    for f in ('r', 'g', 'b', 'tile'):
+        assert (got[f] == pts[f]).all(), f
+    lines = open(fn).read().split("\n")
+    first = lines.index("end_header") + 1
+    assert lines[first] == "%.8g %.8g %.8g %d %d %d %d" % tuple(pts[0].tolist())
+    assert lines[first + len(pts)] == "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 %d 1 0 0" % len(pts)      # the camera record PCL appends
+    # an empty cloud travels too
+    fn = str(tmp_path / "empty.ply")
+    assert cwipc.cwipc_write(fn, cwipc.cwipc_from_points([], 0)) == 0
+    assert cwipc.cwipc_read(fn, 0).count() == 0
+
+
+def test_ply_reader_takes_other_writers_files(cwipc, tmp_path):
+    """Files as other tools write them: doubles, big-endian binary, colour properties missing or in another order, face lists,
+    CRLF line ends, elements in front of the vertices."""
+    import struct
+    fn = str(tmp_path / "doubles_crlf.ply")
+    open(fn, "wb").write(b"ply\r\nformat ascii 1.0\r\ncomment made by hand\r\nelement vertex 2\r\nproperty double x\r\nproperty double y\r\n"
+                         b"property double z\r\nproperty uchar blue\r\nproperty uchar green\r\nproperty uchar red\r\nelement face 1\r\n"
+                         b"property list uchar int vertex_indices\r\nend_header\r\n0.5 -1.25 3 30 20 10\r\n1e-3 2 -3.5 33 22 11\r\n3 0 1 0\r\n")
+    got = cwipc.cwipc_read(fn, 1).get_numpy_array()
+    assert got.tolist() == [(0.5, -1.25, 3.0, 10, 20, 30, 0), (np.float32(1e-3), 2.0, -3.5, 11, 22, 33, 0)]
+    fn = str(tmp_path / "big_endian.ply")
+    body = struct.pack(">3i", 7, 8, 9)                                      # an element in front of the vertices
+    body += struct.pack(">fffBBBBh", 1.5, 2.5, -4.0, 1, 2, 3, 64, -7) + struct.pack(">fffBBBBh", 0.25, 0.0, 8.0, 9, 8, 7, 128, 5)
+    body += struct.pack(">B3i", 3, 0, 1, 0)
+    open(fn, "wb").write(b"ply\nformat binary_big_endian 1.0\nelement misc 1\nproperty int a\nproperty int b\nproperty int c\nelement vertex 2\n"
+                         b"property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+                         b"property uchar alpha\nproperty short extra\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n" + body)
+    got = cwipc.cwipc_read(fn, 1).get_numpy_array()
+    assert got.tolist() == [(1.5, 2.5, -4.0, 1, 2, 3, 64), (0.25, 0.0, 8.0, 9, 8, 7, 128)]
+
+
+def test_ply_errors_are_loud(cwipc, tmp_path):
     pc, _ = _build_pointcloud(cwipc)
     with pytest.raises(cwipc.CwipcError):
         cwipc.cwipc_read(str(tmp_path / "nonexistent.ply"), 1234)
     with pytest.raises(cwipc.CwipcError):
-        cwipc.cwipc_write(str(tmp_path / "out.ply"), pc)
+        cwipc.cwipc_write(str(tmp_path / "no" / "such" / "dir" / "out.ply"), pc)
+    bad = str(tmp_path / "bad.ply")
+    open(bad, "w").write("plywood\n")
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_read(bad, 0)
+    short = str(tmp_path / "short.ply")
+    open(short, "w").write("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n")
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_read(short, 0)
 
 
 def test_debugdump(cwipc, tmp_path):
