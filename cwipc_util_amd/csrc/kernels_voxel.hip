@@ -190,20 +190,41 @@ void first_box(const double p[3], double res, double mn[3], double mx[3], int &d
     }
 }
 
-// The octree key of a coordinate, floor((p - min) / resolution) in double (genOctreeKeyforPoint),
-// is monotone in p: "key >= m" is a threshold test p >= T(m).  Smallest float that passes.
-// Found by bisection over the ordered floats: near zero the double sum p - min absorbs thousands of float steps
-// (a face through a first point with a coordinate of -5e-17 -- a cloud rotated by 270 degrees -- sits ~1e28 float steps
-// away from (float)(min + m * res)), so no fixed-width search around that value is safe.
-float leaf_threshold(double mn0, double res, int m) {
-    const double md = (double)m;
-    const auto passes = [&](float p) { return floor(((double)p - mn0) / res) >= md; };
-    // floats as integers in their numeric order
+// Smallest float for which a monotone predicate (false ... false true ... true over the ordered floats) holds, searched
+// outwards from a guess: doubling steps until the answer is bracketed, then bisection.  The guess is a few float steps
+// off as a rule (a dozen evaluations); it may be ~1e28 steps off near zero, where the double sum p - min absorbs
+// them all (a face through a first point with a coordinate of -5e-17: a cloud rotated by 270 degrees) -- hence no
+// fixed-width search, and hence not 32 bisection steps from the ends of the float line for every one of 768 table
+// entries either (120 us per call for a cloud whose anchor is new, as every tile of a capture is).
+template <class Pred>
+float first_float_where(const Pred &passes, float guess) {
     const auto to_ord = [](float f) { int32_t b; memcpy(&b, &f, 4); return b >= 0 ? (int64_t)b : -(int64_t)(b & 0x7fffffff); };
     const auto from_ord = [](int64_t o) { int32_t b = o >= 0 ? (int32_t)o : (int32_t)(0x80000000u | (uint32_t)(-o)); float f; memcpy(&f, &b, 4); return f; };
-    int64_t lo = to_ord(-FLT_MAX), hi = to_ord(FLT_MAX);   // invariant: lo fails, hi passes (if they do at all)
-    if (passes(from_ord(lo))) return -FLT_MAX;
-    if (!passes(from_ord(hi))) return INFINITY;
+    const int64_t lowest = to_ord(-FLT_MAX), highest = to_ord(FLT_MAX);
+    if (!(guess >= -FLT_MAX && guess <= FLT_MAX)) guess = 0.f;
+    int64_t lo, hi;   // invariant at the end: lo fails, hi passes
+    const int64_t g = to_ord(guess);
+    if (passes(from_ord(g))) {
+        hi = g;
+        int64_t step = 1;
+        for (;;) {
+            lo = hi - step;
+            if (lo <= lowest) { lo = lowest; if (passes(from_ord(lo))) return -FLT_MAX; break; }
+            if (!passes(from_ord(lo))) break;
+            hi = lo;
+            step *= 2;
+        }
+    } else {
+        lo = g;
+        int64_t step = 1;
+        for (;;) {
+            hi = lo + step;
+            if (hi >= highest) { hi = highest; if (!passes(from_ord(hi))) return INFINITY; break; }
+            if (passes(from_ord(hi))) break;
+            lo = hi;
+            step *= 2;
+        }
+    }
     while (hi - lo > 1) {
         const int64_t mid = lo + (hi - lo) / 2;
         if (passes(from_ord(mid))) hi = mid; else lo = mid;
@@ -211,19 +232,16 @@ float leaf_threshold(double mn0, double res, int m) {
     return from_ord(hi);
 }
 
+// The octree key of a coordinate, floor((p - min) / resolution) in double (genOctreeKeyforPoint), is monotone in p:
+// "key >= m" is a threshold test p >= T(m).  Smallest float that passes.
+float leaf_threshold(double mn0, double res, int m) {
+    const double md = (double)m;
+    return first_float_where([&](float p) { return floor(((double)p - mn0) / res) >= md; }, (float)(mn0 + md * res));
+}
+
 // Smallest float whose voxel index floor(fl(p * inv_leaf)) exceeds `voxel` (fp32 product, as the kernels compute it).
 float voxel_upper_bound(float inv_leaf, int voxel) {
-    const auto passes = [&](float p) { return floorf(p * inv_leaf) > (float)voxel; };
-    const auto to_ord = [](float f) { int32_t b; memcpy(&b, &f, 4); return b >= 0 ? (int64_t)b : -(int64_t)(b & 0x7fffffff); };
-    const auto from_ord = [](int64_t o) { int32_t b = o >= 0 ? (int32_t)o : (int32_t)(0x80000000u | (uint32_t)(-o)); float f; memcpy(&f, &b, 4); return f; };
-    int64_t lo = to_ord(-FLT_MAX), hi = to_ord(FLT_MAX);
-    if (passes(from_ord(lo))) return -FLT_MAX;
-    if (!passes(from_ord(hi))) return INFINITY;
-    while (hi - lo > 1) {
-        const int64_t mid = lo + (hi - lo) / 2;
-        if (passes(from_ord(mid))) hi = mid; else lo = mid;
-    }
-    return from_ord(hi);
+    return first_float_where([&](float p) { return floorf(p * inv_leaf) > (float)voxel; }, (float)(((double)voxel + 1.0) / (double)inv_leaf));
 }
 
 // ---------------------------------------------------------------------------
