@@ -1,7 +1,7 @@
 """Condense a profile_round.sh output directory into the text committed under profiles/."""
 import csv, glob, collections, sys, json, os
 out = sys.argv[1]
-print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline")
+print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-config4 --no-config3")
 for l in open(os.path.join(out, "bench_trace.json")):
     if l.startswith("{"):
         d = json.loads(l)
