@@ -10,8 +10,10 @@ Workload (BASELINE.json configs[1]): cwipc_synthetic(npoints=10 000 000) -> N = 
 (640 MB > the 256 MB Infinity Cache) so every step reads cold HBM.
 
 N > 1 (weak scaling): every rank holds one camera tile of the same size (tile mask 1 << rank),
-runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join
-(cwipc_util_amd.multigpu) -- the path's one exchange step.  Frames stream: the join of frame i runs on a
+runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join -- the path's one
+exchange step: RCCL inside the library (cwipc_hip_comm_join, one C call per frame; CWIPC_BENCH_EXCHANGE=torch selects
+the same protocol on torch.distributed, cwipc_util_amd.multigpu, which is also what the bench falls back to, on all
+ranks together, should the library's exchange fail its preflight against it).  Frames stream: the join of frame i runs on a
 worker thread while the main thread downsamples frame i + 1 (at most two frames in flight; all joins are
 complete when the timed region ends).  For N > 1 the library is told to leave 24 compute units out of the
 voxel kernel's persistent grid (CWIPC_SPARE_CUS, unless already set), so that the join's small kernels do not
@@ -261,8 +263,32 @@ def main() -> None:
     joining = world > 1 or force_join
     pipelined = joining and os.environ.get("CWIPC_BENCH_PIPELINE", "1") != "0"
     joiner = None
+    exchange, exchange_note = None, None
     if joining:
-        from cwipc_util_amd.multigpu import join_across_ranks, JoinPipeline
+        from cwipc_util_amd import multigpu
+        from cwipc_util_amd.multigpu import JoinPipeline
+        # "library": RCCL inside libcwipc_util.so, one C call per frame (cwipc_hip_comm_join); "torch": the same protocol on
+        # torch.distributed (multigpu.SlotExchange).  The library's exchange is checked against the other on a real frame first
+        # and all ranks fall back together if any of them disagrees.
+        exchange = os.environ.get("CWIPC_BENCH_EXCHANGE", "library" if backend == "nccl" else "torch")
+        if exchange == "library":
+            try:
+                probe = cwipc.cwipc_downsample(clouds[0], CELLSIZE)
+                a = multigpu.join_across_ranks(probe, exchange="library")
+                b = multigpu.join_across_ranks(probe, exchange="torch")
+                good = a.count() == b.count() and a.timestamp() == b.timestamp() and a.cellsize() == b.cellsize() \
+                    and bool(np.array_equal(a.get_numpy_array(), b.get_numpy_array()))
+                why = "" if good else "results differ from the torch.distributed exchange"
+            except Exception as e:   # noqa: BLE001 -- whatever it is, the bench goes on with the other exchange
+                good, why = False, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([1 if good else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                exchange, exchange_note = "torch", "library exchange failed its preflight on some rank" + (f" (here: {why})" if why else "")
+                print(f"[rank {rank}] {exchange_note}", file=sys.stderr)
+
+        def join_across_ranks(pc):
+            return multigpu.join_across_ranks(pc, exchange=exchange)
     if pipelined:
         import queue
         import threading
@@ -270,7 +296,7 @@ def main() -> None:
         FLUSH = object()
         # CWIPC_BENCH_JOIN_ASYNC=0: the worker waits for every frame's collective before it takes the next frame;
         # default: the collective of frame i is on the wire while frame i + 1 is packed (multigpu.JoinPipeline)
-        join_async = os.environ.get("CWIPC_BENCH_JOIN_ASYNC", "1") != "0"
+        join_async = os.environ.get("CWIPC_BENCH_JOIN_ASYNC", "1") != "0" and exchange == "torch"   # (the library's call never waits for the payload)
 
         class Joiner:
             def __init__(self):
@@ -421,7 +447,8 @@ def main() -> None:
                 "fused_points": fused_points,
                 "input_copies_rotated": NCOPIES,
                 "inputs_resident_in_hbm": True,
-                **({"voxel_kernel_spare_cus": int(os.environ.get("CWIPC_SPARE_CUS", "0"))} if joining else {}),
+                **({"voxel_kernel_spare_cus": int(os.environ.get("CWIPC_SPARE_CUS", "0")), "exchange": exchange} if joining else {}),
+                **({"exchange_note": exchange_note} if exchange_note else {}),
             },
             "roofline": {
                 "bound": "hbm",

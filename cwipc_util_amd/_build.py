@@ -30,6 +30,7 @@ SOURCES = [
     "stubs.cpp",
     "ply.cpp",
     "filters.cpp",
+    "exchange.cpp",
     "kernels_basic.hip",
     "kernels_voxel.hip",
     "kernels_sor.hip",
@@ -93,7 +94,9 @@ def build(force: bool = False, jobs: int = 6, debug_knobs: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(lambda s: _compile(s, force, header_mtime), SOURCES))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
-        cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs
+        # RCCL for the multi-GPU join (exchange.cpp).  Where torch has been imported first its librccl.so.1 is already in the
+        # process and serves this dependency too (same soname), as with the HIP runtime.
+        cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
             raise RuntimeError(f"link failed:\n{proc.stdout}\n{proc.stderr}")

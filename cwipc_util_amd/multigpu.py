@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks", "JoinPipeline"]
+__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks", "JoinPipeline", "library_comm"]
 
 
 def tiles_of_rank(ntiles: int, rank: int, world: int) -> List[int]:
@@ -249,10 +249,36 @@ def _unpack(ex: SlotExchange, counts: List[int], ts: int, cs: float, dev: torch.
     return util.cwipc_hip_from_device_slots(ex.recv.data_ptr(), ex.recv.shape[1], ex.HEADER_ROWS, counts, ts, cs, stream=_torch_stream())
 
 
-def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None):
+_library_comms = {}
+
+
+def library_comm(group: Optional[dist.ProcessGroup] = None):
+    """This rank's end of the exchange INSIDE the library (util.cwipc_hip_comm: RCCL linked into libcwipc_util.so, one C call
+    per frame, nothing of torch on the per-frame path).  torch.distributed only carries the 128-byte id from rank 0 to the
+    others, once; any backend will do for that.  Collective on first use per (group, device)."""
+    from . import util
+    key = (id(group), util.cwipc_util_dll_load().cwipc_hip_get_device())
+    comm = _library_comms.get(key)
+    if comm is None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [util.cwipc_hip_comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        comm = _library_comms[key] = util.cwipc_hip_comm(box[0], rank, world)
+    return comm
+
+
+def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None, exchange: Optional[str] = None):
     """All ranks call this with their (device-resident) cloud, or None for "no tile this frame";
-    every rank gets the fused cloud as a new cwipc_pointcloud_wrapper.  GPU only.  Frame after frame this
-    is one collective (SlotExchange); the library's SoA -> AoS kernel writes straight into the send slot."""
+    every rank gets the fused cloud as a new cwipc_pointcloud_wrapper.  GPU only.
+
+    exchange = "library" (the default on an RCCL group): the library's own exchange, see library_comm().
+    exchange = "torch" (the default on any other backend, e.g. gloo rehearsals): the protocol written out on torch.distributed --
+    frame after frame one collective (SlotExchange); the library's SoA -> AoS kernel writes straight into the send slot."""
+    if exchange is None:
+        exchange = "library" if dist.get_backend(group) == "nccl" else "torch"
+    if exchange == "library":
+        return library_comm(group).join(pc)
     dev = torch.device("cuda", torch.cuda.current_device())
     staged = dist.get_backend(group) != "nccl"   # no device collectives (gloo: rehearsals on one GPU): slots live on the host
     key = (id(group), dev.index, staged)

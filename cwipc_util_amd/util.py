@@ -41,7 +41,7 @@ __all__ = [
     # MI355X extensions (no reference counterpart)
     'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked',
     'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_from_device_slots', 'cwipc_hip_copy_device_aos',
-    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_hip_simulatecams',
+    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_hip_simulatecams', 'cwipc_hip_comm', 'cwipc_hip_comm_unique_id',
 ]
 
 # reference util.py:86, 346, 348
@@ -215,6 +215,12 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_tiles_used': ([cwipc_pointcloud_p, _c.POINTER(_c.c_ubyte)], _c.c_int),
     'cwipc_hip_knn_mean_dist': ([cwipc_pointcloud_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_double), _c.c_float], _c.c_int),
     'cwipc_hip_workspace_bytes': ([], _c.c_size_t),
+    'cwipc_hip_comm_unique_id': ([_c.c_void_p, _c.POINTER(_c.c_char_p)], _c.c_int),
+    'cwipc_hip_comm_create': ([_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_char_p)], _c.c_void_p),
+    'cwipc_hip_comm_free': ([_c.c_void_p], None),
+    'cwipc_hip_comm_rank': ([_c.c_void_p], _c.c_int),
+    'cwipc_hip_comm_nranks': ([_c.c_void_p], _c.c_int),
+    'cwipc_hip_comm_join': ([_c.c_void_p, cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_profile_enable': ([_c.c_int], None),
     'cwipc_hip_profile_reset': ([], None),
     'cwipc_hip_profile_count': ([], _c.c_int),
@@ -836,6 +842,46 @@ def cwipc_hip_simulatecams(pc: cwipc_pointcloud_wrapper, camera_vectors: numpy.n
     rv = cwipc_util_dll_load().cwipc_hip_simulatecams(pc.as_cwipc_p(), int(cams.shape[0]), float(numpy.float32(centroid[0])), float(numpy.float32(centroid[2])),
                                                       cams.ctypes.data)
     return _wrap_filter_result("cwipc_hip_simulatecams", rv)
+
+
+CWIPC_HIP_COMM_ID_BYTES = 128
+CWIPC_HIP_JOIN_LOOPBACK = 1
+
+
+def cwipc_hip_comm_unique_id() -> bytes:
+    """The id one rank makes and hands to the others (by any means) before they all call cwipc_hip_comm(id, rank, nranks)."""
+    buf = ctypes.create_string_buffer(CWIPC_HIP_COMM_ID_BYTES)
+    err = ctypes.c_char_p()
+    if cwipc_util_dll_load().cwipc_hip_comm_unique_id(buf, ctypes.byref(err)) != 0:
+        raise CwipcError("cwipc_hip_comm_unique_id: " + (err.value.decode('utf8') if err.value else "failed"))
+    return buf.raw
+
+
+class cwipc_hip_comm:
+    """This rank's end of the multi-GPU join inside the library (RCCL; include/cwipc_util_amd/hip_ext.h): join(pc) once per
+    frame on every rank, one C call, no torch on the way.  Creation is collective."""
+
+    def __init__(self, unique_id: bytes, rank: int, nranks: int):
+        if len(unique_id) != CWIPC_HIP_COMM_ID_BYTES:
+            raise ValueError("cwipc_hip_comm: the id has %d bytes" % CWIPC_HIP_COMM_ID_BYTES)
+        err = ctypes.c_char_p()
+        self._dll = cwipc_util_dll_load()
+        self._comm = self._dll.cwipc_hip_comm_create(unique_id, rank, nranks, ctypes.byref(err))
+        if not self._comm:
+            raise CwipcError("cwipc_hip_comm_create: " + (err.value.decode('utf8') if err.value else "failed"))
+        self.rank, self.nranks = rank, nranks
+
+    def join(self, pc: Optional[cwipc_pointcloud_wrapper], loopback: bool = False) -> cwipc_pointcloud_wrapper:
+        """The fused cloud of this frame: every rank's points in rank order.  pc = None: no tile on this rank this frame."""
+        if not self._comm:
+            raise CwipcError("cwipc_hip_comm: used after free()")
+        rv = self._dll.cwipc_hip_comm_join(self._comm, pc.as_cwipc_p() if pc is not None else None, CWIPC_HIP_JOIN_LOOPBACK if loopback else 0)
+        return _wrap_filter_result('cwipc_hip_comm_join', rv)
+
+    def free(self) -> None:
+        if self._comm:
+            self._dll.cwipc_hip_comm_free(self._comm)
+            self._comm = None
 
 
 def cwipc_tilefilter_masked(pc: cwipc_pointcloud_wrapper, mask: int) -> cwipc_pointcloud_wrapper:

@@ -51,6 +51,27 @@ _CWIPC_UTIL_EXPORT long cwipc_hip_copy_device_aos_on_stream(cwipc_pointcloud *pc
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_device_slots_on_stream(const void *dev_slots, int nslots, size_t slot_rows, size_t header_rows,
                                                                            const uint32_t *counts, uint64_t timestamp, float cellsize, void *stream);
 
+/* ---- the multi-GPU join: one process per GPU, RCCL inside the library, one call per frame ----
+ * Replaces the reference's in-process fold of cwipc_join over a frame's tiles (python/cwipc/net/source_synchronizer.py:175-188,
+ * src/cwipc_filters.cpp:388-418) when the tiles live on different GPUs.  Bootstrap as with any RCCL communicator: one rank
+ * asks for an id, the application hands its bytes to the other ranks (MPI, a socket, torch.distributed's store ...), every
+ * rank creates its end on the device chosen with cwipc_hip_set_device.  With nranks > 1 the call REFUSES to start unless
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 is in the environment (this image's driver: RCCL's buffer hand-over between processes fails
+ * without it, inside the first collective). */
+#define CWIPC_HIP_COMM_ID_BYTES 128
+typedef struct cwipc_hip_comm cwipc_hip_comm;
+_CWIPC_UTIL_EXPORT int cwipc_hip_comm_unique_id(void *id /* CWIPC_HIP_COMM_ID_BYTES */, char **errorMessage);              /* 0 ok */
+_CWIPC_UTIL_EXPORT cwipc_hip_comm *cwipc_hip_comm_create(const void *id, int rank, int nranks, char **errorMessage);       /* collective */
+_CWIPC_UTIL_EXPORT void cwipc_hip_comm_free(cwipc_hip_comm *comm);
+_CWIPC_UTIL_EXPORT int cwipc_hip_comm_rank(cwipc_hip_comm *comm);
+_CWIPC_UTIL_EXPORT int cwipc_hip_comm_nranks(cwipc_hip_comm *comm);
+/* Every rank calls this once per frame with its cloud (NULL: no tile this frame) and gets the fused cloud: the ranks' points in
+ * rank order, timestamp and cellsize the minimum over the clouds that took part (src/cwipc_filters.cpp:411-414).  One
+ * ncclAllGather of 32 bytes per rank, then one group of ncclSend/ncclRecv that moves the planes straight into the result; the
+ * call returns when the group is enqueued (the result carries an event).  NULL on error (logged). */
+#define CWIPC_HIP_JOIN_LOOPBACK 1   /* this rank's own part travels through RCCL too (send/recv to itself): exercises the exchange on one GPU */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *comm, cwipc_pointcloud *pc, int flags);
+
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid);

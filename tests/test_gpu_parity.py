@@ -1191,9 +1191,10 @@ def test_join_pipeline_on_the_device_path(gpu, oracle, synth):
         pts, cs = synth(100000)
         frames = [pts[:3000], pts[:3500], pts[:0], pts[5000:5000 + 40000], pts[:100], pts[:90000], pts[200:700]]
         clouds = [make_cloud(gpu, f, cs, 1000 + i) for i, f in enumerate(frames)]
-        for pc, f in zip(clouds, frames):
-            out = join_across_ranks(pc)
-            assert same(out.get_numpy_array(), f) and out.timestamp() == pc.timestamp()
+        for exchange in ("torch", "library", None):   # None: the default, the library's own exchange on an RCCL group
+            for pc, f in zip(clouds, frames):
+                out = join_across_ranks(pc, exchange=exchange)
+                assert same(out.get_numpy_array(), f) and out.timestamp() == pc.timestamp() and out.cellsize() == pc.cellsize(), exchange
         pipe = JoinPipeline()
         got = [pipe.submit(pc) for pc in clouds] + [pipe.flush()]
         assert got[0] is None
@@ -1202,6 +1203,60 @@ def test_join_pipeline_on_the_device_path(gpu, oracle, synth):
         assert pipe.flush() is None
     finally:
         dist.destroy_process_group()
+
+
+def test_library_exchange_on_one_rank(gpu, oracle, synth):
+    """The exchange inside the library (cwipc_hip_comm_join: RCCL linked into libcwipc_util.so) on a one-rank communicator, no
+    torch.distributed anywhere: the plain call (one rank: the result holds the input's planes) and the loopback flavour, where the
+    record all-gather and the four planes really travel through ncclAllGather / ncclSend / ncclRecv (to this rank itself) and
+    land at their displacement in a result of their own.  Frames of changing size, an empty cloud, no cloud, and results that
+    outlive their input."""
+    import gc
+    comm = gpu.cwipc_hip_comm(gpu.cwipc_hip_comm_unique_id(), 0, 1)
+    try:
+        pts, cs = synth(100000)
+        frames = [pts[:3000], pts[:3501], pts[:0], pts[5000:5000 + 40000], pts[:1], pts[:90000], pts[200:703]]
+        for loopback in (False, True):
+            for i, f in enumerate(frames):
+                pc = make_cloud(gpu, f, cs, 1000 + i)
+                gpu.cwipc_hip_upload(pc, drop_host_copy=True)
+                out = comm.join(pc, loopback=loopback)
+                pc.free(force=True)          # the sends may still be reading it: the library keeps the planes until they have
+                del pc
+                gc.collect()
+                filler = make_cloud(gpu, pts[:len(f)][::-1].copy(), cs, 1)   # takes what the freed input gave back to the pool
+                gpu.cwipc_hip_upload(filler)
+                assert same(out.get_numpy_array(), f), (loopback, i)
+                assert out.timestamp() == 1000 + i and out.cellsize() == np.float32(cs)
+            none = comm.join(None, loopback=loopback)
+            assert none.count() == 0 and none.timestamp() == 0 and none.cellsize() == 0.0
+        # a result of a filter that is still running when the join is called (deferred downsample results settle inside)
+        pc = make_cloud(gpu, pts, cs, 5)
+        want = check_downsample(gpu, oracle, pts, cs, 0.02)[0]
+        for _ in range(4):
+            out = comm.join(gpu.cwipc_downsample(pc, 0.02), loopback=True)
+            assert same(out.get_numpy_array(), want) and out.cellsize() == np.float32(0.02)
+    finally:
+        comm.free()
+    with pytest.raises(gpu.CwipcError):
+        comm.join(None)
+
+
+def test_library_exchange_refuses_what_cannot_work(gpu, monkeypatch):
+    """Between processes RCCL needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver: without it the communicator is refused at
+    creation (before any rank can be left waiting inside a collective); bad ranks and ids are refused too."""
+    uid = gpu.cwipc_hip_comm_unique_id()
+    assert len(uid) == 128
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    with pytest.raises(gpu.CwipcError, match="HSA_ENABLE_IPC_MODE_LEGACY"):
+        gpu.cwipc_hip_comm(uid, 0, 2)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    with pytest.raises(gpu.CwipcError, match="HSA_ENABLE_IPC_MODE_LEGACY"):
+        gpu.cwipc_hip_comm(uid, 1, 2)
+    with pytest.raises(gpu.CwipcError):
+        gpu.cwipc_hip_comm(uid, 3, 2)
+    with pytest.raises(ValueError):
+        gpu.cwipc_hip_comm(uid[:64], 0, 1)
 
 
 def test_results_that_share_planes_outlive_their_input(gpu, oracle, synth):
