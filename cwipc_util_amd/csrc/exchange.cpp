@@ -246,8 +246,8 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_point
     if (n_me && !loopback) {
         k::JoinPart part{src->x(), src->y(), src->z(), src->rgbt(), n_me, disp[cm->rank]};
         k::join_copy(part, *dst, cm->stream);
-        if (hipGetLastError() != hipSuccess) {
-            hip_failed(hipGetLastError(), who, __FILE__, __LINE__);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            hip_failed(e, who, __FILE__, __LINE__);
             (void)hipStreamSynchronize(cm->stream);
             return nullptr;
         }

@@ -341,7 +341,19 @@ extern "C" cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int np
         k::join_copy(part, *dst, c.stream);
         off += src[i]->npoints;
     }
-    if (!c.sync()) return nullptr;
+    if (profiling_enabled()) {
+        if (!c.sync()) return nullptr;
+        return wrap(dst, ts, cellsize);
+    }
+    // the copies need no more attention from the host: the result goes out with them still running (it carries an event),
+    // the inputs stay until they have been read
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+        hip_failed(e, "cwipc_join", __FILE__, __LINE__);
+        (void)c.sync();
+        return nullptr;
+    }
+    dst->mark_pending(c.stream);
+    for (int i = 0; i < npc; i++) if (src[i]->npoints) src[i]->note_reader(c.stream);
     return wrap(dst, ts, cellsize);
 }
 
@@ -418,24 +430,24 @@ extern "C" cwipc_pointcloud *cwipc_remove_outliers(cwipc_pointcloud *pc, int kNe
     if (!perTile) {   // :262-268
         return wrap(sor_once(*src, kNeighbors, stddevMulThresh), pc->timestamp(), pc->cellsize());
     }
-    // :238-261 -- distinct tiles in first-appearance order.  The tile plane is one
-    // byte per point: fetch it and scan on the host (N bytes over PCIe is small
-    // next to the k-NN work that follows).
+    // :238-261 -- distinct tiles in first-appearance order: a kernel leaves the index of every tile value's first point
+    // in 256 words, the host sorts the tiles that occur by it (1 KB read back, the tile plane stays where it is).
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     size_t n = src->npoints;
     std::vector<int> tiles;
     if (n) {
-        uint32_t *stage = (uint32_t *)c.staging(n * sizeof(uint32_t));
-        if (!stage) return nullptr;
-        bool ok = hipMemcpyAsync(stage, src->rgbt(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+        uint32_t *dev_first = (uint32_t *)c.device_scratch(256 * sizeof(uint32_t));
+        uint32_t *first = (uint32_t *)c.staging(256 * sizeof(uint32_t));
+        if (!dev_first || !first) return nullptr;
+        k::tile_first_index(*src, dev_first, c.stream);
+        bool ok = hipMemcpyAsync(first, dev_first, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
         ok = c.sync() && ok;
         if (!ok) return nullptr;
-        bool seen[256] = {false};
-        for (size_t i = 0; i < n && tiles.size() < 256; i++) {
-            int t = (int)(stage[i] >> 24);
-            if (!seen[t]) { seen[t] = true; tiles.push_back(t); }
-        }
+        std::vector<std::pair<uint32_t, int>> order;
+        for (int t = 0; t < 256; t++) if (first[t] != 0xffffffffu) order.emplace_back(first[t], t);
+        std::sort(order.begin(), order.end());
+        for (auto &o : order) tiles.push_back(o.second);
     }
     std::vector<std::shared_ptr<DeviceSoA>> parts;
     size_t total = 0;

@@ -315,6 +315,8 @@ void synthetic_fill(const DeviceSoA &dst, int hsteps, int asteps, float m_angle,
 void map_cameras(const DeviceSoA &src, const DeviceSoA &dst, int ncam, float cen_x, float cen_z, const double *dirs, hipStream_t s);
 // ORs the set of tile values that occur into 8 device words
 void tiles_used(const DeviceSoA &src, uint32_t *dev_bits8, hipStream_t s);
+// first256[t] = index of the first point with tile value t, 0xffffffff if there is none (256 device words)
+void tile_first_index(const DeviceSoA &src, uint32_t *dev_first256, hipStream_t s);
 // colorize: dev_table = 256 entries of {double cw[3]; double valid;} followed by 256 doubles old/255.0, then (1-w).
 void map_colorize(const DeviceSoA &src, const DeviceSoA &dst, const double *dev_table, hipStream_t s);
 

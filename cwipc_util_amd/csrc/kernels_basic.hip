@@ -582,6 +582,29 @@ void tiles_used(const DeviceSoA &src, uint32_t *dev_bits8, hipStream_t s) {
     CW_LAUNCH("tiles_used", tiles_used_kernel, dim3(grid_for(n, BLOCK) > 1024 ? 1024 : grid_for(n, BLOCK)), dim3(BLOCK), 0, s, src.rgbt(), n, dev_bits8);
 }
 
+// first[t] = index of the first point with tile value t (0xffffffff: none): what the per-tile outlier filter needs to
+// visit the tiles in first-appearance order (reference src/cwipc_filters.cpp:238-250) without the tile plane leaving the device.
+// The plain read in front of the LDS atomic filters all but the first few touches of a tile per workgroup.
+__global__ void __launch_bounds__(BLOCK) tile_first_kernel(const uint32_t *__restrict__ rgbt, size_t n, uint32_t *__restrict__ first) {
+    __shared__ uint32_t local[256];
+    for (int t = threadIdx.x; t < 256; t += BLOCK) local[t] = 0xffffffffu;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const uint32_t t = rgbt[i] >> 24;
+        if (((volatile uint32_t *)local)[t] > (uint32_t)i) atomicMin(&local[t], (uint32_t)i);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 256; t += BLOCK)
+        if (local[t] != 0xffffffffu) atomicMin(&first[t], local[t]);
+}
+
+void tile_first_index(const DeviceSoA &src, uint32_t *dev_first256, hipStream_t s) {
+    const size_t n = src.npoints;
+    (void)hipMemsetAsync(dev_first256, 0xff, 256 * sizeof(uint32_t), s);
+    if (!n) return;
+    CW_LAUNCH("tile_first_index", tile_first_kernel, dim3(grid_for(n, BLOCK) > 1024 ? 1024 : grid_for(n, BLOCK)), dim3(BLOCK), 0, s, src.rgbt(), n, dev_first256);
+}
+
 // ---------------------------------------------------------------------------
 // join: plane-wise concatenation
 // ---------------------------------------------------------------------------

@@ -110,6 +110,8 @@ enum {
     C_ERR = 0, C_COUNT = 1, C_DEPTH = 2, C_EVENTS = 3, C_SHIFT = 4 /* 3 x int64 */, C_MINB = 10, C_DIVB = 13,
     C_FALLBACK = 16,   // runs that found the workgroup table full and went to the global records one lane at a time
     C_MAXLOAD = 17,    // fullest workgroup table (entries)
+    // 18: C_SCATTER (voxel_partition.inc)
+    C_FLUSHED = 19,    // table entries flushed by all workgroups = global record updates of the pass (the general variant counts them)
     C_SEQ = 31,        // number of published words (the host copy carries the pass's sequence number in the upper half of each 64-bit word)
     C_WORDS = 32
 };
@@ -1100,6 +1102,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         // how the table fared: the host sizes the workgroups of the next call by it
         if (L.nfallback) atomicAdd(&W.ctrl[C_FALLBACK], L.nfallback);
         atomicMax(&W.ctrl[C_MAXLOAD], L.nused);
+        if (L.nused) atomicAdd(&W.ctrl[C_FLUSHED], L.nused);
     }
     if (!P.want_list) {
         // octree path: the finalize pass finds the records through the occupancy bitmaps, so the count is
@@ -1117,6 +1120,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 }
 
 #include "voxel_k1_fast.inc"
+#include "voxel_partition.inc"
 
 // ---------------------------------------------------------------------------
 // K2: octree bounding-box replay / global grid box
@@ -1790,6 +1794,8 @@ struct PendingVoxel : DeferredResult {
     float cellsize = 0;
     bool known = false, ok = false, settled = false;
     uint32_t err = 0, m = 0;
+    bool partitioned = false;                    // the pass ran on a partitioned copy of the cloud ...
+    uint32_t scatter = 0, steps_total = 0;       //   ... and this is how scattered the cloud was as it came (of how many wave steps)
     bool outcome_locked();                       // waits for the replay kernel's report; true: spec_dst holds the result
     bool outcome() { std::lock_guard<std::recursive_mutex> g(lock); return outcome_locked(); }
     std::shared_ptr<DeviceSoA> settle() override;
@@ -1827,7 +1833,10 @@ struct Workspace {
     uint32_t *gbits = nullptr;         // plain grid: bitmap over the VoxelGrid index space, its per-word and per-block prefixes
     uint32_t *gprefix = nullptr, *gblock = nullptr;
     size_t gwords_cap = 0;
-    float *bboxes = nullptr;
+    float *bboxes = nullptr;           // [2][bbox_cap][6]: the ranges' boxes the replay kernel reads; behind them room for boxes nobody reads
+    float *part = nullptr;             // partition pass: the cloud moved into spatial buckets, four planes of part_stride elements
+    size_t part_stride = 0;
+    uint32_t *part_hist = nullptr;     //   ... and its PART_BUCKETS bucket counts / cursors
     uint32_t *ctrl = nullptr;
     uint32_t *bitmaps = nullptr;
     uint32_t *seg_count = nullptr;
@@ -1836,6 +1845,11 @@ struct Workspace {
     double faces_mn0[3] = {0, 0, 0};   //   ... and what it was computed from
     double faces_res = 0;
     bool faces_valid = false;
+    void drop_partition_buffers() {
+        if (part) { (void)hipFree(part); g_workspace_bytes -= 16 * part_stride; }
+        if (part_hist) (void)hipFree(part_hist);
+        part = nullptr; part_hist = nullptr; part_stride = 0;
+    }
     void release() {
         // also runs at thread exit, when the runtime may be gone: errors ignored
         if (head) (void)hipFree(head);
@@ -1847,6 +1861,7 @@ struct Workspace {
         if (gblock) (void)hipFree(gblock);
         gbits = gprefix = gblock = nullptr; gwords_cap = 0;
         if (bboxes) (void)hipFree(bboxes);
+        drop_partition_buffers();
         if (faces) (void)hipFree(faces);
         if (host_words) (void)hipHostFree(host_words);
         host_words = nullptr;
@@ -1922,6 +1937,7 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         const int lds_fast = (int)sizeof(FastTable);
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&partition_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         ws.device = dev;
     }
     if (ws.leaf_cap < leaf_cap) {
@@ -1955,7 +1971,7 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
     if (ws.bbox_cap < nranges) {
         if (ws.bboxes) (void)hipFree(ws.bboxes);
         ws.bboxes = nullptr; ws.bbox_cap = 0;
-        CW_HIP_TRY(hipMalloc((void **)&ws.bboxes, (size_t)nranges * 6 * sizeof(float)));
+        CW_HIP_TRY(hipMalloc((void **)&ws.bboxes, 2 * (size_t)nranges * 6 * sizeof(float)));
         ws.bbox_cap = nranges;
     }
     if (!ws.faces) CW_HIP_TRY(hipMalloc((void **)&ws.faces, FACE_TABLE_WORDS * sizeof(uint32_t)));
@@ -2031,6 +2047,7 @@ bool PendingVoxel::outcome_locked() {
     known = true;
     err = seen ? hw[C_ERR] : 0x80000000u;
     m = seen ? hw[C_COUNT] : 0u;
+    scatter = seen ? hw[C_SCATTER] : 0xffffffffu;
     ok = seen && err == 0u && m <= spec_cap;
     return ok;
 }
@@ -2076,6 +2093,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.pending.reset();
         if (p->outcome()) {
             ws.last_m = p->m;
+            // (a partitioned pass tells how scattered the cloud was as it came: in scan order again, no partition next time)
+            if (p->partitioned && (size_t)p->scatter * 4 < p->steps_total) ws.incoherent = false;
         } else {
             ws.last_m = 0;
             ws.streak = 0;
@@ -2193,6 +2212,27 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         for (int a = 0; a < 3; a++) P.ib[a] = 2;   // bricks of 64 voxels aligned to the voxel lattice
     }
 
+    // Points in no spatial order (learned from the calls before: the workgroup tables overflowed whatever the workgroup size):
+    // move them into coarse spatial buckets first and accumulate the moved copy (voxel_partition.inc).
+    static const bool partition_off = []() { const char *e = getenv("CWIPC_VOXEL_PARTITION"); return e && atoi(e) == 0; }();   // test knob
+    const bool partition = ws.incoherent && !partition_off && n >= 65536;
+    const size_t part_stride = (n + 1023) & ~(size_t)1023;
+    if (partition) {
+        if (ws.part_stride < part_stride) {
+            ws.drop_partition_buffers();
+            if (hipMalloc((void **)&ws.part, 16 * part_stride) != hipSuccess || hipMalloc((void **)&ws.part_hist, (size_t)PART_BUCKETS * PART_PAD * sizeof(uint32_t)) != hipSuccess) {
+                (void)hipGetLastError();
+                ws.drop_partition_buffers();
+                hip_failed(hipErrorOutOfMemory, "voxel partition buffers", __FILE__, __LINE__);
+                return nullptr;
+            }
+            ws.part_stride = part_stride;
+            g_workspace_bytes += 16 * part_stride;
+        }
+    } else if (ws.part) {
+        ws.drop_partition_buffers();   // (nothing of this workspace's stream is in flight: its last pass has reported above or long ago)
+    }
+
     uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 16;   // 16 grids = 0.33 GB (a person-sized cloud at 1 cm has 12 to 16 leaves); grown x4 when a cloud has more
     int mode = leaf_split ? 1 : 0;
     bool used_fast = false;
@@ -2240,7 +2280,27 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         // The fast variant takes coherent clouds that fit its workgroup table and key; it says so (ERR_FAST_PATH) when a
         // cloud does not, and the pass is run again with the general variant (which is remembered for the clouds to come).
         static const bool fast_off = []() { const char *e = getenv("CWIPC_VOXEL_GENERAL"); return e && atoi(e) != 0; }();   // test knob: general variant only
-        const bool fast = mode != 2 && !ws.no_fast && ws.shrink == 0 && !fast_off;
+        const bool fast = mode != 2 && !ws.no_fast && ws.shrink == 0 && !fast_off && !partition;
+        // the planes the accumulate kernel reads, and where it leaves its boxes
+        const float *kx = src.x(), *ky = src.y(), *kz = src.z();
+        const uint32_t *kw = src.rgbt();
+        VoxWork Wk = W;
+        if (partition) {
+            float *px = ws.part, *py = px + ws.part_stride, *pz = py + ws.part_stride;
+            uint32_t *pw = (uint32_t *)(pz + ws.part_stride);
+            const uint32_t padded = (uint32_t)((n + WAVE_STEP - 1) / WAVE_STEP * WAVE_STEP);
+            if (hipMemsetAsync(ws.part_hist, 0, (size_t)PART_BUCKETS * PART_PAD * sizeof(uint32_t), c.stream) != hipSuccess) {
+                hip_failed(hipGetLastError(), "voxel partition setup", __FILE__, __LINE__);
+                return nullptr;
+            }
+            CW_LAUNCH("partition_count", partition_count_kernel, dim3(nblocks), dim3(K1_THREADS), 0, c.stream, (uint32_t)n, (uint32_t)P.per_wave, P.inv_leaf,
+                      src.x(), src.y(), src.z(), ws.bboxes, ws.part_hist, ws.ctrl);
+            CW_LAUNCH("partition_scan", partition_scan_kernel, dim3(1), dim3(K1_THREADS), 0, c.stream, ws.part_hist);
+            CW_LAUNCH("partition_scatter", partition_scatter_kernel, dim3((unsigned)((n + PART_CHUNK - 1) / PART_CHUNK)), dim3(K1_THREADS), sizeof(PartLds), c.stream,
+                      (uint32_t)n, padded, P.inv_leaf, src.x(), src.y(), src.z(), src.rgbt(), px, py, pz, pw, ws.part_hist);
+            kx = px; ky = py; kz = pz; kw = pw;
+            Wk.bboxes = ws.bboxes + (size_t)ws.bbox_cap * 6;   // the boxes of the moved points: nobody reads them
+        }
         used_fast = fast;
         if (fast) {
             FastParams F;
@@ -2262,14 +2322,11 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                           src.y(), src.z(), src.rgbt(), W);
             }
         } else if (mode == 0) {
-            CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
-                      src.z(), src.rgbt(), W);
+            CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);
         } else if (mode == 1) {
-            CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(), src.y(),
-                      src.z(), src.rgbt(), W);
+            CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);
         } else {
-            CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, src.x(),
-                      src.y(), src.z(), src.rgbt(), W);
+            CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);
         }
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
                   ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), ws.host_words, seq);
@@ -2307,6 +2364,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             p->seq = seq;
             p->spec_cap = spec_cap;
             p->cellsize = cellsize;
+            p->partitioned = partition;
+            p->steps_total = (uint32_t)steps_total;
             src.note_reader(c.stream);   // the input's planes are not recycled before the accumulate kernel is done with them
             ws.pending = p;
             *deferred = p;
@@ -2371,7 +2430,17 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         {
             // adapt the workgroup size for the next call
             const uint32_t fallbacks = hw[C_FALLBACK], maxload = hw[C_MAXLOAD];
-            if (ws.incoherent) {
+            if (partition) {
+                // how scattered the cloud was as it came: in scan order again -> no partition next time
+                if ((size_t)hw[C_SCATTER] * 4 < steps_total) ws.incoherent = false;
+            } else if (!used_fast && !err && n >= 65536 && 2 * ((size_t)hw[C_FLUSHED] + fallbacks) > n && n > 4 * (size_t)hw[C_COUNT]) {
+                // Voxels hold several points each, and yet most points went to the global records on their own (a cloud in scan
+                // order: one update per ~90 points at the 10 M configuration): the workgroups' ranges are all over the place.
+                // The partition pass takes such clouds from the next call on.
+                ws.incoherent = true;
+                ws.shrink = 0;
+                ws.calm = 0;
+            } else if (ws.incoherent) {
                 // nothing to adapt: this kind of cloud defeats the table whatever its size
             } else if (ws.shrink >= 2 && (size_t)fallbacks * 2 > n) {
                 ws.incoherent = true;   // smaller workgroups did not help: points in no order at all

@@ -389,6 +389,40 @@ def test_downsample_permuted_input(gpu, oracle, synth):
     check_downsample(gpu, oracle, pts[perm], cs, -0.01)
 
 
+def test_downsample_stream_of_permuted_frames_goes_through_the_partition_pass(gpu, oracle, synth):
+    """After a few calls on clouds in no spatial order the library moves the points into spatial buckets in front of the
+    accumulate kernel (voxel_partition.inc).  The octree's shape depends on the order of the points AS THEY CAME, so every
+    call of the stream must still equal the oracle's walk over the permuted cloud: octree variant (leaf lattice, growth
+    history) and plain grid, with points that do not count in between; then the same cloud in scan order (the partition
+    switches itself off again) -- results checked the same way throughout."""
+    pts, cs = synth(300000)
+    rng = np.random.default_rng(77)
+    perm = pts[rng.permutation(len(pts))]
+    for cellsize in (0.01, -0.01):
+        if cellsize > 0:   # (pcl::VoxelGrid on a dense cloud does not skip them: the plain grid is tested without, as everywhere here)
+            perm['x'][1000] = np.nan
+            perm['z'][250000] = np.inf
+        else:
+            perm['x'][1000], perm['z'][250000] = 0.0, 0.0
+        pc = make_cloud(gpu, perm, cs, 4242)
+        exp, exp_cs = oracle.downsample(perm, cs, cellsize)
+        for call in range(8):
+            got = gpu.cwipc_downsample(pc, cellsize).get_numpy_array()
+            assert len(got) == len(exp), (cellsize, call, len(got), len(exp))
+            for f in ('r', 'g', 'b', 'tile'):
+                assert (got[f] == exp[f]).all(), (cellsize, call, f)
+            for f in ('x', 'y', 'z'):
+                assert np.abs(got[f].astype(np.float64) - exp[f]).max() <= XYZ_TOL, (cellsize, call, f)
+        check_downsample(gpu, oracle, pts, cs, cellsize)
+        check_downsample(gpu, oracle, pts, cs, cellsize)
+    if os.environ.get("CWIPC_VOXEL_PARTITION") != "0":
+        with gpu.cwipc_hip_profile() as prof:
+            pc = make_cloud(gpu, perm, cs, 1)
+            for call in range(6):
+                gpu.cwipc_downsample(pc, 0.01)
+        assert "partition_scatter" in prof.kernels, sorted(prof.kernels)
+
+
 def test_downsample_shifted_and_rotated(gpu, oracle, synth):
     """Clouds away from the origin, negative coordinates, several octree growth steps in every direction."""
     pts, cs = synth(100000)
