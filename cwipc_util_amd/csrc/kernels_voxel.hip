@@ -111,6 +111,7 @@ enum {
     C_FALLBACK = 16,   // runs that found the workgroup table full and went to the global records one lane at a time
     C_MAXLOAD = 17,    // fullest workgroup table (entries)
     // 18: C_SCATTER (voxel_partition.inc)
+    C_LEAVES = 20,     // octree leaves (or bricks of the plain grid) the pass has met = leaf grids in use
     C_FLUSHED = 19,    // table entries flushed by all workgroups = global record updates of the pass (the general variant counts them)
     C_SEQ = 31,        // number of published words (the host copy carries the pass's sequence number in the upper half of each 64-bit word)
     C_WORDS = 32
@@ -257,6 +258,7 @@ __device__ __forceinline__ uint32_t leaf_lookup(const VoxWork &W, uint32_t mask,
         if (cur == k) return pos;
         if (cur == 0ull) {
             unsigned long long old = atomicCAS(&W.leaf_keys[pos], 0ull, k);
+            if (old == 0ull) atomicAdd(&W.ctrl[C_LEAVES], 1u);
             if (old == 0ull || old == k) return pos;
         }
         pos = (pos + 1) & mask;
@@ -1796,6 +1798,7 @@ struct PendingVoxel : DeferredResult {
     uint32_t err = 0, m = 0;
     bool partitioned = false;                    // the pass ran on a partitioned copy of the cloud ...
     uint32_t scatter = 0, steps_total = 0;       //   ... and this is how scattered the cloud was as it came (of how many wave steps)
+    uint32_t leaves = 0;                         // leaf grids the pass used
     bool outcome_locked();                       // waits for the replay kernel's report; true: spec_dst holds the result
     bool outcome() { std::lock_guard<std::recursive_mutex> g(lock); return outcome_locked(); }
     std::shared_ptr<DeviceSoA> settle() override;
@@ -1821,6 +1824,20 @@ struct Workspace {
     bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
     bool no_fast = false;              // the fast accumulate kernel gave this kind of cloud back (ERR_FAST_PATH): use the general one
     int streak = 0;                    // octree passes of this kind in a row that went through without a retry
+    int roomy = 0;                     // passes in a row that used at most a quarter of the leaf grids
+    uint32_t shrink_to = 0;            // != 0: give the grids back and start again with this many (at the next call, when nothing is in flight)
+    // A leaf grid is 20 MB: a thread that once met a cloud of many leaves must not sit on them while it filters camera tiles
+    // of three or four.  Eight roomy passes in a row -> the next call reallocates for what these passes needed.
+    void note_leaves(uint32_t leaves) {
+        uint32_t need = 4;
+        while (need < leaves) need <<= 1;
+        if (need * 4 <= leaf_cap) {
+            if (++roomy >= 8) shrink_to = need;
+        } else {
+            roomy = 0;
+            shrink_to = 0;
+        }
+    }
     uint32_t *host_words = nullptr;    // page-locked: the replay kernel publishes the pass's control words here (64-bit, tagged with seq)
     std::shared_ptr<struct PendingVoxel> pending;   // the pass still in flight on this workspace, if the call that started it has returned
     size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
@@ -2048,6 +2065,7 @@ bool PendingVoxel::outcome_locked() {
     err = seen ? hw[C_ERR] : 0x80000000u;
     m = seen ? hw[C_COUNT] : 0u;
     scatter = seen ? hw[C_SCATTER] : 0xffffffffu;
+    leaves = seen ? hw[C_LEAVES] : 0u;
     ok = seen && err == 0u && m <= spec_cap;
     return ok;
 }
@@ -2082,8 +2100,17 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     const size_t n = src.npoints;
-    const int which = t_ws_next;
-    t_ws_next ^= 1;
+    // Two workspaces (and streams) per thread, taken in turn, so that a call queued right behind another does not wait for
+    // that one's finalize kernel.  The second one comes into being only when it is needed: a thread whose downsample calls
+    // are separated by other work (a per-tile filter chain) finds its first workspace idle every time and never pays the
+    // 80+ MB of grids for a second.
+    int which = t_ws_next;
+    if (!t_ws.ws[1]) {
+        which = 0;
+        if (t_ws.ws[0] && c.stream && hipStreamQuery(c.stream) == hipErrorNotReady) which = 1;
+        (void)hipGetLastError();   // (hipErrorNotReady is an answer, not a failure)
+    }
+    t_ws_next = which ^ 1;
     Workspace &ws = t_ws.get(which);
     StreamOfWorkspace on_its_stream(c, which);
     if (ws.pending) {
@@ -2093,6 +2120,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.pending.reset();
         if (p->outcome()) {
             ws.last_m = p->m;
+            ws.note_leaves(p->leaves);
             // (a partitioned pass tells how scattered the cloud was as it came: in scan order again, no partition next time)
             if (p->partitioned && (size_t)p->scatter * 4 < p->steps_total) ws.incoherent = false;
         } else {
@@ -2233,7 +2261,21 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.drop_partition_buffers();   // (nothing of this workspace's stream is in flight: its last pass has reported above or long ago)
     }
 
-    uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : 16;   // 16 grids = 0.33 GB (a person-sized cloud at 1 cm has 12 to 16 leaves); grown x4 when a cloud has more
+    if (ws.shrink_to && ws.shrink_to < ws.leaf_cap) {
+        // (this thread's last pass on the workspace may have its finalize kernel in flight still)
+        if (!c.sync()) return nullptr;
+        if (ws.head) (void)hipFree(ws.head);
+        if (ws.records) (void)hipFree(ws.records);
+        if (ws.bitmaps) (void)hipFree(ws.bitmaps);
+        ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr; ws.records = nullptr; ws.bitmaps = nullptr;
+        g_workspace_bytes -= ws.grid_bytes;
+        ws.grid_bytes = 0;
+        ws.leaf_cap = 0;
+    }
+    // 4 grids = 80 MB to begin with (a camera tile at 1 cm has 2 to 4 leaves, a person-sized cloud 12 to 16); x4 when a cloud has more
+    uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : (ws.shrink_to ? ws.shrink_to : 4);
+    if (ws.shrink_to) ws.roomy = 0;
+    ws.shrink_to = 0;
     int mode = leaf_split ? 1 : 0;
     bool used_fast = false;
     for (int attempt = 0; attempt < 10; attempt++) {
@@ -2618,6 +2660,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             return soa_alloc(0);
         }
         if (leaf_split) ws.streak = attempt == 0 ? ws.streak + 1 : 0;
+        ws.note_leaves(hw[C_LEAVES]);
         return dst;
     }
     cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: could not size the workspace");

@@ -214,6 +214,46 @@ def test_config5_stream_through_the_server(gpu, oracle):
     assert len(server.times_grab) == nframes and sync.core.missing_per_occurrence == []
 
 
+def test_config5_eight_threads_workspace_footprint(gpu):
+    """Eight decoder-like threads, each running the per-tile chain of config 5 on its own 300 k-point tile frame after frame
+    (reference net/source_synchronizer.py:128-149: one thread per tile).  A thread whose downsample calls are separated by
+    other filters holds ONE voxel workspace (the second exists only for back-to-back calls); its leaf grids (20 MB each) are
+    sized from what the thread's clouds need and shrink again after eight roomy passes.  A tile of this capture is the whole
+    synthetic figure (12 to 16 octree leaves of 0.64 m at 1 cm), so a workspace is 16 grids = 0.32 GB: eight threads and this
+    one hold ~3.2 GB.  Round 1 held 21 GB here (64 grids x 2 workspaces per thread)."""
+    import threading
+    from cwipc_util_amd.capture import capture_tile
+    from cwipc_util_amd.filters import factory
+    dll = gpu.util.cwipc_util_dll_load()
+    tiles = [capture_tile(300_000, t, NTILES) for t in range(NTILES)]
+    counts, errors = {}, []
+
+    def work(t):
+        try:
+            flt = [factory('colorize(0.8, "camera")'), factory('voxelize(0.01)'), factory('remove_outliers(16, 1.0, False)')]
+            seen = set()
+            for _ in range(24):
+                cur = tiles[t]
+                for f in flt:
+                    cur = f.filter(cur)
+                seen.add(cur.count())
+            counts[t] = seen
+        except Exception as e:   # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(NTILES)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors
+    assert all(len(counts[t]) == 1 for t in range(NTILES)), counts      # every frame of a tile gives the same cloud
+    # this thread's own workspaces may be sized for the 10 M-point clouds of earlier tests: the same rule shrinks them
+    for _ in range(20):
+        gpu.cwipc_downsample(tiles[0], 0.01).count()
+    dll.cwipc_hip_synchronize()
+    held = dll.cwipc_hip_workspace_bytes()
+    assert held <= 3.5 * 10**9, held
+
+
 @pytest.fixture(scope="module")
 def full_cloud(oracle):
     return oracle.synthetic(10_000_000, 0.0)
