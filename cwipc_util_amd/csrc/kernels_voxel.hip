@@ -32,23 +32,34 @@
 //                         is exactly "p >= T(m)" for one float T(m)).
 //   K1 voxel_accumulate   persistent: one 1024-lane workgroup per CU, every wave streams a
 //                         contiguous range of the planes (dwordx4 per plane per lane, next
-//                         step prefetched in registers).  fp32/integer only: voxel index,
-//                         leaf by threshold compare, fixed-point offset.  Lanes merge their own
-//                         4 points, DPP row shifts merge runs across lanes, and only run ends
-//                         touch the workgroup's LDS hash table (packed 64-bit LDS atomics).
-//                         The table is flushed ONCE per workgroup into dense per-leaf grids of
-//                         64-byte records, 8 lanes per record, with returning 64-bit adds (the
-//                         returned count tells the first toucher; first touches are listed per
-//                         workgroup and appended with one global atomic).  All sums are
+//                         step prefetched in registers).  fp32/integer only.  Two variants with
+//                         identical integer sums: the fast one (voxel_k1_fast.inc: linear voxel
+//                         keys, leaf side bits from per-wave slabs, wave-wide prefix sums, one
+//                         conflict-free LDS insert per run) takes clouds in scan order; the general
+//                         one below (leaf by threshold compare, DPP segmented scan over chains of
+//                         lanes, overflow path to the global records) takes everything else and is
+//                         what the fast one hands a cloud back to (ERR_FAST_PATH).  Either way the
+//                         workgroup's LDS table is flushed ONCE into dense per-leaf grids of
+//                         64-byte records, 8 lanes per record; first touches (told by the returned
+//                         count, in the fast variant by the leaf's occupancy bit) are counted per
+//                         bitmap slice.  All sums are
 //                         integers: results are bitwise reproducible.  Each wave also emits the
 //                         bounding box of its range.
+//   (partition)           clouds in no spatial order first go through voxel_partition.inc: bucket
+//                         histogram + range boxes of the original order, scan, LDS-staged scatter;
+//                         K1 (general) then runs on the moved copy.
 //   K2 octree_replay      one workgroup replays the octree's bounding-box growth over the wave
 //                         boxes, re-reading only the ranges that trigger a growth step
-//                         (plain grid: reduces the boxes to the global one).
-//   K3 make_sort_keys     one lane per occupied voxel: 64-bit output-order key.
-//   (radix sort of the ~40 k keys)
-//   K4 emit_and_clean     gathers the records in output order, writes the planes and zeroes
-//                         what it read, so the workspace is clean for the next call.
+//                         (plain grid: reduces the boxes to the global one); publishes the pass's
+//                         control words to pinned host memory.
+//   rank_emit             octree path: output position = rank of the cell's bit in the occupancy
+//                         bitmaps (leaves in Morton order of their final keys), centroid / colour /
+//                         tile from the record, record and bit zeroed for the next call.  Launched
+//                         right behind K2, before the host knows the count; a stream of frames gets
+//                         its results back while these kernels run (PendingVoxel).
+//   grid_mark .. unmark   plain grid: the same through a bitmap over the VoxelGrid index space.
+//   make_sort_keys + rocprim radix sort + emit_and_clean: only for plain-grid index spaces beyond
+//                         2^28 cells.
 #include "internal.hpp"
 
 #include <atomic>
