@@ -208,6 +208,13 @@ def main() -> None:
     ap.add_argument("--config4-steps", type=int, default=30)
     args = ap.parse_args()
 
+    # Exactly ONE line goes to stdout: the JSON line.  Libraries that print there on their own (RCCL writes a five-line
+    # version banner to stdout when a communicator is made) are sent to stderr: descriptor 1 points at stderr until the
+    # line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -473,13 +480,18 @@ def main() -> None:
             result["config3"] = config3
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pts, pc_cellsize)
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(result), flush=True)   # (flushed here: nothing that happens at interpreter exit may cost the line)
+        os.dup2(2, 1)
 
     if joiner is not None:
         joiner.todo.put(None)
         joiner.thread.join()
     if dist is not None:
         dist.barrier()
+        if joining:
+            multigpu.free_library_comms()
         dist.destroy_process_group()
 
 

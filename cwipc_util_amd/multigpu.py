@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks", "JoinPipeline", "library_comm"]
+__all__ = ["tiles_of_rank", "all_gatherv_points", "SlotExchange", "join_across_ranks", "JoinPipeline", "library_comm", "free_library_comms"]
 
 
 def tiles_of_rank(ntiles: int, rank: int, world: int) -> List[int]:
@@ -266,6 +266,13 @@ def library_comm(group: Optional[dist.ProcessGroup] = None):
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         comm = _library_comms[key] = util.cwipc_hip_comm(box[0], rank, world)
     return comm
+
+
+def free_library_comms() -> None:
+    """Destroy the library-side communicators made by library_comm() (every rank, before the process group goes)."""
+    for comm in _library_comms.values():
+        comm.free()
+    _library_comms.clear()
 
 
 def join_across_ranks(pc, group: Optional[dist.ProcessGroup] = None, exchange: Optional[str] = None):

@@ -7,7 +7,7 @@ out = '/tmp/isa/%s.s' % os.path.basename(src)
 os.makedirs('/tmp/isa', exist_ok=True)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 subprocess.run(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-I' + root + '/include', '-I' + root + '/cwipc_util_amd/csrc',
-                '-DCWIPC_VERSION=x', '-x', 'hip', '-S', '--cuda-device-only', src, '-o', out], check=True, stderr=subprocess.DEVNULL)
+                '-DCWIPC_VERSION=x', *([] if not os.environ.get('DBG') else ['-DCWIPC_DEBUG_KNOBS']), '-x', 'hip', '-S', '--cuda-device-only', src, '-o', out], check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
 meta = {}
 for blk in s.split('  - .agpr_count:')[1:]:
