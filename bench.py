@@ -278,19 +278,39 @@ def main() -> None:
         # torch.distributed (multigpu.SlotExchange).  The library's exchange is checked against the other on a real frame first
         # and all ranks fall back together if any of them disagrees.
         exchange = os.environ.get("CWIPC_BENCH_EXCHANGE", "library" if backend == "nccl" else "torch")
+        abandon_at_exit = False
         if exchange == "library":
-            try:
-                probe = cwipc.cwipc_downsample(clouds[0], CELLSIZE)
-                a = multigpu.join_across_ranks(probe, exchange="library")
-                b = multigpu.join_across_ranks(probe, exchange="torch")
-                good = a.count() == b.count() and a.timestamp() == b.timestamp() and a.cellsize() == b.cellsize() \
-                    and bool(np.array_equal(a.get_numpy_array(), b.get_numpy_array()))
-                why = "" if good else "results differ from the torch.distributed exchange"
-            except Exception as e:   # noqa: BLE001 -- whatever it is, the bench goes on with the other exchange
-                good, why = False, f"{type(e).__name__}: {e}"
-            flag = torch.tensor([1 if good else 0], dtype=torch.int32, device="cuda")
+            # the preflight runs on a thread of its own with a time limit: two ranks on RCCL have never run where this was
+            # written (one GPU), and a bench that hangs measures nothing.  A rank whose preflight does not come back leaves
+            # that thread behind, all ranks fall back to the torch exchange together, and the process ends with os._exit.
+            import threading
+            verdict = {}
+
+            def preflight():
+                try:
+                    torch.cuda.set_device(device_index)
+                    probe = cwipc.cwipc_downsample(clouds[0], CELLSIZE)
+                    a = multigpu.join_across_ranks(probe, exchange="library")
+                    b = multigpu.join_across_ranks(probe, exchange="torch")
+                    good = a.count() == b.count() and a.timestamp() == b.timestamp() and a.cellsize() == b.cellsize() \
+                        and bool(np.array_equal(a.get_numpy_array(), b.get_numpy_array()))
+                    verdict["good"], verdict["why"] = good, "" if good else "results differ from the torch.distributed exchange"
+                except Exception as e:   # noqa: BLE001 -- whatever it is, the bench goes on with the other exchange
+                    verdict["good"], verdict["why"] = False, f"{type(e).__name__}: {e}"
+
+            th = threading.Thread(target=preflight, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("CWIPC_BENCH_PREFLIGHT_S", "120")))
+            if th.is_alive():
+                verdict.setdefault("good", False)
+                verdict.setdefault("why", "no answer within the time limit")
+                abandon_at_exit = True
+            good, why = verdict.get("good", False), verdict.get("why", "")
+            # (second word: does any rank leave a stuck thread behind?  Then every rank ends with os._exit, none waits for another)
+            flag = torch.tensor([1 if good else 0, 0 if abandon_at_exit else 1], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+            abandon_at_exit = int(flag[1].item()) == 0
+            if int(flag[0].item()) == 0:
                 exchange, exchange_note = "torch", "library exchange failed its preflight on some rank" + (f" (here: {why})" if why else "")
                 print(f"[rank {rank}] {exchange_note}", file=sys.stderr)
 
@@ -485,6 +505,9 @@ def main() -> None:
         print(json.dumps(result), flush=True)   # (flushed here: nothing that happens at interpreter exit may cost the line)
         os.dup2(2, 1)
 
+    if joining and abandon_at_exit:
+        sys.stderr.flush()
+        os._exit(0)   # a thread of this process is still inside a collective that never completed
     if joiner is not None:
         joiner.todo.put(None)
         joiner.thread.join()
