@@ -73,12 +73,37 @@ __global__ void __launch_bounds__(BLK) bbox_kernel(const float *__restrict__ x, 
 }
 
 // ---- occupancy probe / counting sort ----
+// Consecutive points of a cloud in scan order mostly share a cell: one atomic per RUN of equal cells inside a wave, not per
+// point (the scattered atomics of these two kernels were their whole cost: 10 M of them take ~0.4 ms).  `run` describes the
+// run a lane belongs to: its first lane and its length.
+struct WaveRun { int first; int length; bool leads; };
+__device__ __forceinline__ WaveRun wave_run(uint32_t c, bool active) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t prev = (uint32_t)__shfl_up((int)c, 1, 64);
+    const bool leads = active && (lane == 0 || prev != c);
+    const unsigned long long L = __ballot(leads), A = __ballot(active);
+    WaveRun r;
+    r.leads = leads;
+    const unsigned long long upto = L & ((2ull << lane) - 1ull);                 // leaders at or below this lane
+    r.first = upto ? 63 - __builtin_clzll(upto) : lane;
+    const unsigned long long above = r.first < 63 ? (L >> (r.first + 1)) : 0ull;  // the next run's leader, if any
+    const int end = above ? r.first + 1 + __builtin_ctzll(above) : (A ? 64 - __builtin_clzll(A) : 0);
+    r.length = end - r.first;
+    return r;
+}
+
 __global__ void __launch_bounds__(BLK) cell_count_kernel(Grid g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                                                         size_t n, uint32_t *__restrict__ counts, uint32_t *__restrict__ cell_id) {
-    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
-        uint32_t c = cell_of(g, x[i], y[i], z[i]);
-        if (cell_id) cell_id[i] = c;
-        atomicAdd(&counts[c], 1u);
+    for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
+        const size_t i = base + threadIdx.x;
+        const bool active = i < n;
+        uint32_t c = 0xffffffffu;
+        if (active) {
+            c = cell_of(g, x[i], y[i], z[i]);
+            if (cell_id) cell_id[i] = c;
+        }
+        const WaveRun r = wave_run(c, active);
+        if (r.leads) atomicAdd(&counts[c], (uint32_t)r.length);
     }
 }
 
@@ -107,10 +132,16 @@ __global__ void __launch_bounds__(BLK) count_nonzero_kernel(const uint32_t *__re
 __global__ void __launch_bounds__(BLK) cell_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
                                                           const uint32_t *__restrict__ cell_id, const uint32_t *__restrict__ cell_start,
                                                           uint32_t *__restrict__ cell_fill, float4 *__restrict__ sorted) {
-    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
-        uint32_t c = cell_id[i];
-        uint32_t pos = cell_start[c] + atomicAdd(&cell_fill[c], 1u);
-        sorted[pos] = make_float4(x[i], y[i], z[i], __uint_as_float((uint32_t)i));
+    for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
+        const size_t i = base + threadIdx.x;
+        const bool active = i < n;
+        const uint32_t c = active ? cell_id[i] : 0xffffffffu;
+        const WaveRun r = wave_run(c, active);
+        // the run's leader reserves room for the whole run; the order of points inside a cell does not matter to the search
+        uint32_t at = 0;
+        if (r.leads) at = cell_start[c] + atomicAdd(&cell_fill[c], (uint32_t)r.length);
+        at = (uint32_t)__shfl((int)at, r.first, 64);
+        if (active) sorted[at + (uint32_t)((threadIdx.x & 63) - r.first)] = make_float4(x[i], y[i], z[i], __uint_as_float((uint32_t)i));
     }
 }
 
@@ -222,6 +253,16 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
             }
         }
     };
+    // a range of candidates, four loads in flight at a time (the loop is latency-bound otherwise: one dependent 16-byte
+    // load per lane and iteration)
+    auto scan = [&](uint32_t first, uint32_t last) {
+        uint32_t e = first;
+        for (; e + 4 <= last; e += 4) {
+            const float4 p0 = sorted[e], p1 = sorted[e + 1], p2 = sorted[e + 2], p3 = sorted[e + 3];
+            candidate(p0); candidate(p1); candidate(p2); candidate(p3);
+        }
+        for (; e < last; e++) candidate(sorted[e]);
+    };
     // Cells that are neighbours along x are neighbours in `sorted` (the counting sort runs x fastest), so a
     // row of cells x0..x1 is ONE range of points: two index loads per row instead of two per cell.
     auto row_range = [&](int x0, int x1, int y, int z, uint32_t &first, uint32_t &last) {
@@ -249,12 +290,12 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
             const float t = fmaxf(d - eps, 0.f);
             return t * t;
         };
-        for (uint32_t e = first[4]; e < last[4]; e++) candidate(sorted[e]);
+        scan(first[4], last[4]);
 #pragma unroll
         for (int r = 0; r < 9; r++) {
             if (r == 4) continue;
             if (gap(q.y, ylo, r % 3 - 1) + gap(q.z, zlo, r / 3 - 1) >= best[KCAP - 1]) continue;
-            for (uint32_t e = first[r]; e < last[r]; e++) candidate(sorted[e]);
+            scan(first[r], last[r]);
         }
     }
     const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
@@ -271,15 +312,15 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
                     uint32_t first, last;
                     if (face) {   // the whole row belongs to the shell
                         row_range(x0, x1, y, z, first, last);
-                        for (uint32_t e = first; e < last; e++) candidate(sorted[e]);
+                        scan(first, last);
                     } else {      // only its two end cells do
                         if (cx - ring >= 0) {
                             row_range(cx - ring, cx - ring, y, z, first, last);
-                            for (uint32_t e = first; e < last; e++) candidate(sorted[e]);
+                            scan(first, last);
                         }
                         if (cx + ring < g.dim[0]) {
                             row_range(cx + ring, cx + ring, y, z, first, last);
-                            for (uint32_t e = first; e < last; e++) candidate(sorted[e]);
+                            scan(first, last);
                         }
                     }
                 }

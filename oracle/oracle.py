@@ -224,3 +224,30 @@ def offset_scale(pts: np.ndarray, x: float, y: float, z: float, scale: float) ->
 def tiles_used(pts: np.ndarray):
     """reference python/cwipc/registration/util.py:285-293 (get_tiles_used)."""
     return sorted(np.unique(_pts(pts)['tile']).tolist())
+
+
+def simulatecams(matrix: np.ndarray, ncamera: int) -> np.ndarray:
+    """SimulatecamsFilter with hard = True, restated (reference python/cwipc/filters/simulatecams.py:17-30, 40-58, 70): the tile
+    of every row of an N x 7 float32 point matrix.  Camera c looks along (cos, 0, sin) of 2 pi c / ncamera; the centroid is
+    numpy's float32 mean of the coordinates with y set to 0; a point's vector is its float32 position, y = 0, minus the centroid
+    (float32 arithmetic), its dot products with the float64 camera vectors are taken one by one (numpy.dot of a float32 and a
+    float64 vector: products and sum in float64, in index order), and the camera is the LAST index of numpy.argsort -- the
+    highest dot product, ties going to the higher camera index of the sorted order.  Pure numpy, row by row as the reference
+    does it: for small inputs."""
+    m = np.asarray(matrix, dtype=np.float32)
+    cams = np.zeros((ncamera, 3), dtype=float)
+    for c in range(ncamera):
+        a = 2 * np.pi * c / ncamera
+        cams[c, 0], cams[c, 2] = np.cos(a), np.sin(a)
+    centroid = np.mean(m[:, :3], axis=0)
+    centroid[1] = 0.0
+    tiles = np.zeros(len(m), dtype=np.uint8)
+    for i in range(len(m)):
+        v = np.array(m[i, :3])
+        v[1] = 0.0
+        v -= centroid
+        dots = np.zeros(ncamera, dtype=float)
+        for c in range(ncamera):
+            dots[c] = np.dot(v, cams[c])
+        tiles[i] = 1 << int(np.argsort(dots)[::-1][0])
+    return tiles

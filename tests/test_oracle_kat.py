@@ -219,3 +219,17 @@ def test_path_vectors_are_reproduced(oracle):
     assert same(oracle.colormap(pts, 0x00ff00ff, 0x05000007), d["colormap"])
     assert same(oracle.tilemap(pts, bytes((i * 7 + 3) % 256 for i in range(256))), d["tilemap"])
     assert same(oracle.join(pts[:100], pts[300:]), d["join"])
+
+
+def test_simulatecams_restatement_against_the_reference_vectors():
+    """oracle.simulatecams against tiles produced by the reference's own SimulatecamsFilter(hard=True)
+    (tests/golden/make_simulatecams_vectors.py ran /root/reference/python/cwipc/filters/simulatecams.py in isolation)."""
+    import os
+    from oracle import oracle as o
+    data = np.load(os.path.join(os.path.dirname(__file__), "golden", "simulatecams_vectors.npz"))
+    names = sorted(k[:-3] for k in data.keys() if k.endswith("_in"))
+    assert len(names) >= 5
+    for name in names:
+        m, ncam, want = data[name + "_in"], int(data[name + "_ncam"]), data[name + "_tile"]
+        got = o.simulatecams(m, ncam)
+        assert (got == want).all(), (name, int((got != want).sum()))
