@@ -235,22 +235,23 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
     for (int j = 0; j < KCAP; j++) best[j] = j < pad ? -INFINITY : INFINITY;
     int have = 0;
     // one candidate: FLANN L2_Simple<float> distance (separately rounded fp32 operations, x,y,z order), sorted insert
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 qxy = {q.x, q.y};
     auto candidate = [&](const float4 p) {
-        float d = __fsub_rn(q.x, p.x);
-        float d2 = __fmul_rn(d, d);
-        d = __fsub_rn(q.y, p.y);
-        d2 = __fadd_rn(d2, __fmul_rn(d, d));
-        d = __fsub_rn(q.z, p.z);
-        d2 = __fadd_rn(d2, __fmul_rn(d, d));
+        // (x and y as one packed subtraction and one packed multiplication: the same separately rounded fp32 operations,
+        // summed in the same order)
+        const f32x2 dxy = qxy - f32x2{p.x, p.y};
+        const f32x2 sq = dxy * dxy;
+        const float dz = __fsub_rn(q.z, p.z);
+        const float d2 = __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));
         if (d2 < best[KCAP - 1]) {
             have++;
-            float v = d2;   // the last register's old value drops out
+            // sorted insert, the largest value drops out: the new j-th smallest is the MEDIAN of the old (j-1)-th, the old
+            // j-th and the newcomer -- one v_med3_f32 per slot, all from old values (top down, in place), no chain of
+            // dependent min / max pairs (which was most of this kernel's instruction count)
 #pragma unroll
-            for (int j = 0; j < KCAP; j++) {
-                const float lo = fminf(best[j], v);
-                v = fmaxf(best[j], v);
-                best[j] = lo;
-            }
+            for (int j = KCAP - 1; j >= 1; j--) best[j] = __builtin_amdgcn_fmed3f(best[j - 1], best[j], d2);
+            best[0] = fminf(best[0], d2);
         }
     };
     // a range of candidates, four loads in flight at a time (the loop is latency-bound otherwise: one dependent 16-byte
