@@ -35,7 +35,14 @@ struct Grid {
     int dim[3];
     double h;
     double inv_h;
+    int nsegx;   // sparse layout: segments (16 cells along x) per row of cells
 };
+
+// Sparse layout of the grid for big clouds.  A surface occupies a percent or two of a fine 3-D grid: clearing and scanning a
+// dense array of 10^8 cells costs more than the search saves.  Cells are grouped into SEGMENTS of 16 along x; only
+// segments that hold points get cells, numbered in the order of the segments (x fastest), so the cells of a row of the
+// grid are still one contiguous run of the sorted points, whatever segments are missing in between.
+constexpr int SEG = 16, SEG_SHIFT = 4;
 
 __device__ __forceinline__ int cell_coord(const Grid &g, float v, int a) {
     int c = (int)floor(((double)v - (double)g.mn[a]) * g.inv_h);
@@ -145,6 +152,73 @@ __global__ void __launch_bounds__(BLK) cell_scatter_kernel(const float *__restri
     }
 }
 
+// ---- sparse layout: which segments exist, their cells ----
+// id of a point's cell before the segments are numbered: segment << 4 | cell inside the segment
+__device__ __forceinline__ uint32_t seg_cell_of(const Grid &g, float x, float y, float z) {
+    const uint32_t cx = (uint32_t)cell_coord(g, x, 0);
+    const uint32_t seg = (cx >> SEG_SHIFT) + (uint32_t)g.nsegx * ((uint32_t)cell_coord(g, y, 1) + (uint32_t)g.dim[1] * (uint32_t)cell_coord(g, z, 2));
+    return (seg << SEG_SHIFT) | (cx & (SEG - 1));
+}
+
+// masks[segment] |= bit of the cell; cell_id[i] = seg_cell_of(point i)
+__global__ void __launch_bounds__(BLK) seg_mark_kernel(Grid g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
+                                                      uint32_t *__restrict__ masks, uint32_t *__restrict__ cell_id) {
+    for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
+        const size_t i = base + threadIdx.x;
+        const bool active = i < n;
+        uint32_t c = 0xffffffffu;
+        if (active) {
+            c = seg_cell_of(g, x[i], y[i], z[i]);
+            cell_id[i] = c;
+        }
+        const WaveRun r = wave_run(c, active);
+        if (r.leads) atomicOr(&masks[c >> SEG_SHIFT], 1u << (c & (SEG - 1)));
+    }
+}
+
+// flags[s] = segment s holds points; out[0] += occupied cells, out[1] += occupied segments (one atomic pair per workgroup)
+__global__ void __launch_bounds__(BLK) seg_census_kernel(const uint32_t *__restrict__ masks, size_t nseg, uint32_t *__restrict__ flags, uint32_t *__restrict__ out) {
+    __shared__ uint32_t wsum[2][BLK / 64];
+    uint32_t cells = 0, segs = 0;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nseg; i += (size_t)gridDim.x * BLK) {
+        const uint32_t m = masks[i];
+        flags[i] = m != 0u;
+        cells += (uint32_t)__popc(m);
+        segs += m != 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { cells += __shfl_down(cells, off, 64); segs += __shfl_down(segs, off, 64); }
+    if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = cells; wsum[1][threadIdx.x >> 6] = segs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+        for (int w = 0; w < BLK / 64; w++) { a += wsum[0][w]; b += wsum[1][w]; }
+        if (a) atomicAdd(&out[0], a);
+        if (b) atomicAdd(&out[1], b);
+    }
+}
+
+// info[s] = (number of occupied segments before s) << 1 | (s is occupied): for an empty segment the first half names the
+// next occupied one, which is what a range lookup wants from it
+__global__ void __launch_bounds__(BLK) seg_pack_kernel(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ before, size_t nseg, uint32_t *__restrict__ info) {
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nseg; i += (size_t)gridDim.x * BLK) info[i] = (before[i] << 1) | flags[i];
+}
+
+// cell_id[i]: seg_cell_of -> number of the cell among the cells that exist; counts[cell]++ (one atomic per run, as above)
+__global__ void __launch_bounds__(BLK) seg_count_kernel(const uint32_t *__restrict__ info, size_t n, uint32_t *__restrict__ cell_id, uint32_t *__restrict__ counts) {
+    for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
+        const size_t i = base + threadIdx.x;
+        const bool active = i < n;
+        uint32_t c = 0xffffffffu;
+        if (active) {
+            const uint32_t sc = cell_id[i];
+            c = ((info[sc >> SEG_SHIFT] >> 1) << SEG_SHIFT) | (sc & (SEG - 1));
+            cell_id[i] = c;
+        }
+        const WaveRun r = wave_run(c, active);
+        if (r.leads) atomicAdd(&counts[c], (uint32_t)r.length);
+    }
+}
+
 // ---- exact k-NN mean distance ----
 // One lane per point (in cell order, so a wave's lanes search the same shells).
 // best[] lives in LDS, one column per lane: best[j * QB + lane].
@@ -222,7 +296,9 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid g, const float4 
 // The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
 // compare-exchange chain, no LDS round trips per accepted candidate.  Unused leading slots hold -inf,
 // so the largest kept distance is always the last register.
-template <int KCAP>
+// SPARSE: cell_start is indexed by the cells that exist (one entry more than there are cells: the end), cell_count is the
+// segment table (seg_pack_kernel).
+template <int KCAP, bool SPARSE>
 __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const float4 *__restrict__ sorted, size_t n, const uint32_t *__restrict__ cell_start,
                                                               const uint32_t *__restrict__ cell_count, int k, float *__restrict__ dist_out) {
     const int want = k + 1, pad = KCAP - want;
@@ -267,6 +343,15 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
     // Cells that are neighbours along x are neighbours in `sorted` (the counting sort runs x fastest), so a
     // row of cells x0..x1 is ONE range of points: two index loads per row instead of two per cell.
     auto row_range = [&](int x0, int x1, int y, int z, uint32_t &first, uint32_t &last) {
+        if (SPARSE) {
+            // the cells of this row that exist, from the first at or after x0 to the last at or before x1: an empty segment's
+            // entry names the next segment that exists, whose first cell is where everything before it ends
+            const uint32_t rowseg = (uint32_t)g.nsegx * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
+            const uint32_t i0 = cell_count[rowseg + ((uint32_t)x0 >> SEG_SHIFT)], i1 = cell_count[rowseg + ((uint32_t)x1 >> SEG_SHIFT)];
+            first = cell_start[((i0 >> 1) << SEG_SHIFT) + ((i0 & 1u) ? ((uint32_t)x0 & (SEG - 1)) : 0u)];
+            last = cell_start[((i1 >> 1) << SEG_SHIFT) + ((i1 & 1u) ? ((uint32_t)x1 & (SEG - 1)) + 1u : 0u)];
+            return;
+        }
         const uint32_t base = (uint32_t)g.dim[0] * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
         const uint32_t c1 = base + (uint32_t)x1;
         first = cell_start[base + (uint32_t)x0];
@@ -292,9 +377,12 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const flo
             return t * t;
         };
         scan(first[4], last[4]);
+        // (rows that share a face with the query's row before the diagonal ones: the sooner the list holds near points,
+        // the more rows and candidates the bound turns away)
+        constexpr int order[8] = {1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-            if (r == 4) continue;
+        for (int o = 0; o < 8; o++) {
+            const int r = order[o];
             if (gap(q.y, ylo, r % 3 - 1) + gap(q.z, zlo, r / 3 - 1) >= best[KCAP - 1]) continue;
             scan(first[r], last[r]);
         }
@@ -422,12 +510,112 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         }
         g.h = h;
         g.inv_h = 1.0 / h;
+        g.nsegx = (g.dim[0] + SEG - 1) / SEG;
         return g;
     };
     auto cells_of = [](const Grid &g) { return (size_t)g.dim[0] * (size_t)g.dim[1] * (size_t)g.dim[2]; };
+    // ---- big clouds: the sparse layout (segments of 16 cells, only those that hold points) ----
+    static const int sparse_knob = []() { const char *e = getenv("CWIPC_SOR_SPARSE"); return e ? atoi(e) : -1; }();   // test knob: 1 always, 0 never
+    if ((sparse_knob == 1 || (sparse_knob != 0 && n >= ((size_t)1 << 20))) && k + 1 <= 33) {
+        static const size_t sparse_cpp = []() { const char *e = getenv("CWIPC_SOR_SPARSE_CELLS_PER_POINT"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)16; }();
+        // cells of the (virtual) fine grid: a few dozen per point, and segment numbers must fit 27 bits
+        const size_t budget = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)1 << 16, sparse_cpp * n));
+        auto segs_of = [](const Grid &gg) { return (size_t)gg.nsegx * (size_t)gg.dim[1] * (size_t)gg.dim[2]; };
+        double hs = maxext / 2048.0;
+        while (cells_of(make_grid(hs)) > budget || segs_of(make_grid(hs)) >= ((size_t)1 << 27)) hs *= 1.25;
+        Grid g = make_grid(hs);
+        size_t nseg = segs_of(g);
+        uint32_t *cell_id = (uint32_t *)pool_alloc(n * sizeof(uint32_t));
+        float4 *sorted = (float4 *)pool_alloc(n * sizeof(float4));
+        uint32_t *masks = nullptr, *flags = nullptr, *before = nullptr, *info = nullptr, *counts = nullptr, *starts = nullptr, *cursor = nullptr;
+        void *scan_tmp = nullptr;
+        auto give_back = [&](bool later) {
+            void *all[] = {cell_id, sorted, masks, flags, before, info, counts, starts, cursor, scan_tmp};
+            for (void *b : all) { if (later) c.free_later(b); else pool_free(b); }
+        };
+        auto fail = [&]() { (void)c.sync(); give_back(false); return false; };
+        if (!cell_id || !sorted) return fail();
+        uint32_t occ_cells = 0, occ_segs = 0;
+        auto census = [&]() -> bool {
+            pool_free(masks); pool_free(flags);
+            masks = (uint32_t *)pool_alloc(nseg * sizeof(uint32_t) + 256);
+            flags = (uint32_t *)pool_alloc(nseg * sizeof(uint32_t));
+            if (!masks || !flags) return false;
+            uint32_t *out = masks + nseg;
+            bool good = hipMemsetAsync(masks, 0, nseg * sizeof(uint32_t) + 8, c.stream) == hipSuccess;
+            if (!good) return false;
+            CW_LAUNCH("sor_seg_mark", seg_mark_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, src.x(), src.y(), src.z(), n, masks, cell_id);
+            CW_LAUNCH("sor_seg_census", seg_census_kernel, dim3(std::min(1024u, grid_for(nseg))), dim3(BLK), 0, c.stream, masks, nseg, flags, out);
+            good = hipMemcpyAsync(c.host_words, out, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+            good = c.sync() && good;
+            occ_cells = c.host_words[0];
+            occ_segs = c.host_words[1];
+            return good;
+        };
+        if (!census()) return fail();
+        {
+            // coarsen so that an occupied cell holds about (k + 1) / 2 points (surface-like data: points per cell grow with h^2)
+            const double ppc = (double)n / (double)(occ_cells ? occ_cells : 1);
+            double target = (double)(k + 1) / 2.0;
+            if (const char *t = getenv("CWIPC_SOR_CELL_TARGET")) target = (double)(k + 1) * atof(t);
+            if (ppc < target) {
+                double h = hs * sqrt(target / ppc);
+                if (h > maxext) h = maxext;
+                g = make_grid(h);
+                nseg = segs_of(g);
+                if (!census()) return fail();
+            }
+        }
+        const size_t ncomp = (size_t)occ_segs << SEG_SHIFT;
+        before = (uint32_t *)pool_alloc(nseg * sizeof(uint32_t));
+        info = (uint32_t *)pool_alloc(nseg * sizeof(uint32_t));
+        counts = (uint32_t *)pool_alloc((ncomp + 1) * sizeof(uint32_t));
+        starts = (uint32_t *)pool_alloc((ncomp + 1) * sizeof(uint32_t));
+        cursor = (uint32_t *)pool_alloc((ncomp + 1) * sizeof(uint32_t));
+        if (!before || !info || !counts || !starts || !cursor) return fail();
+        size_t tmp_a = 0, tmp_b = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, tmp_a, flags, before, 0u, nseg, rocprim::plus<uint32_t>(), c.stream);
+        if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tmp_b, counts, starts, 0u, ncomp + 1, rocprim::plus<uint32_t>(), c.stream);
+        const size_t tmp_bytes = std::max(tmp_a, tmp_b);
+        if (e == hipSuccess) {
+            scan_tmp = pool_alloc(tmp_bytes ? tmp_bytes : 256);
+            if (!scan_tmp) e = hipErrorOutOfMemory;
+        }
+        if (e != hipSuccess) { hip_failed(e, "rocprim::exclusive_scan", __FILE__, __LINE__); return fail(); }
+        if (profiling_enabled()) profile_begin("sor_exclusive_scan", c.stream);
+        e = rocprim::exclusive_scan(scan_tmp, tmp_a, flags, before, 0u, nseg, rocprim::plus<uint32_t>(), c.stream);
+        if (profiling_enabled()) profile_end(c.stream);
+        bool ok = e == hipSuccess;
+        if (ok) CW_LAUNCH("sor_seg_pack", seg_pack_kernel, dim3(std::min(2048u, grid_for(nseg))), dim3(BLK), 0, c.stream, flags, before, nseg, info);
+        ok = ok && hipMemsetAsync(counts, 0, (ncomp + 1) * sizeof(uint32_t), c.stream) == hipSuccess &&
+             hipMemsetAsync(cursor, 0, (ncomp + 1) * sizeof(uint32_t), c.stream) == hipSuccess;
+        if (ok) {
+            CW_LAUNCH("sor_cell_count", seg_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, info, n, cell_id, counts);
+            if (profiling_enabled()) profile_begin("sor_exclusive_scan", c.stream);
+            e = rocprim::exclusive_scan(scan_tmp, tmp_b, counts, starts, 0u, ncomp + 1, rocprim::plus<uint32_t>(), c.stream);
+            if (profiling_enabled()) profile_end(c.stream);
+            ok = e == hipSuccess;
+        }
+        if (ok) {
+            CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts,
+                      cursor, sorted);
+            const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
+            if (k + 1 <= 17) {
+                CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, true>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, info, k, dev_dist);
+            } else {
+                CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, true>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, info, k, dev_dist);
+            }
+        }
+        ok = hipGetLastError() == hipSuccess && ok;
+        if (!ok) { hip_failed(e != hipSuccess ? e : hipGetLastError(), "sor k-NN (sparse grid)", __FILE__, __LINE__); return fail(); }
+        give_back(true);   // (no wait here: every caller has one further down, and the temporaries go back to the pool there)
+        return true;
+    }
+
     // finest cell size whose dense grid stays within MAX_CELLS
     // (and, for small clouds, within a few cells per point: the probe is a pass over the grid)
-    const size_t probe_cells = std::min<size_t>(MAX_CELLS, std::max<size_t>((size_t)1 << 16, 8 * n));
+    static const size_t cells_per_point = []() { const char *e = getenv("CWIPC_SOR_CELLS_PER_POINT"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)8; }();   // tuning knob
+    const size_t probe_cells = std::min<size_t>(MAX_CELLS, std::max<size_t>((size_t)1 << 16, cells_per_point * n));
     double h_min = maxext / 1024.0;
     while (cells_of(make_grid(h_min)) > probe_cells) h_min *= 1.25;
 
@@ -494,9 +682,9 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
         const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
         if (k + 1 <= 17) {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_reg_kernel<17>, dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
         } else if (k + 1 <= 33) {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_reg_kernel<33>, dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
         } else {
             CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, sorted, n, starts, counts, k, dev_dist);
         }

@@ -683,6 +683,52 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
             assert same(got, np.load(os.path.join(tmp, "out_%s.npy" % c))), c
 
 
+def test_sor_sparse_and_dense_grid_layouts_agree(gpu, oracle, synth):
+    """The k-NN grid has two layouts: dense (small clouds) and segments of 16 cells that exist only where points are (big
+    clouds, kernels_sor.hip).  d_i is a property of the cloud, not of the search structure: both layouts, forced through
+    CWIPC_SOR_SPARSE in processes of their own, must give the oracle's d_i bit for bit -- on the synthetic figure, on a thin
+    wide cloud whose rows cross many empty segments, on a cloud with far outliers (empty space between), with non-finite
+    points, and for k beyond 16 (the 33-slot variant)."""
+    import subprocess, sys, tempfile
+    rng = np.random.default_rng(11)
+    clouds = {}
+    pts, cs = synth(60000, 0.2)
+    clouds["figure"] = pts
+    wide = oracle.empty(20000)
+    wide['x'] = rng.random(20000) * 40 - 20; wide['y'] = rng.random(20000) * 0.02; wide['z'] = rng.random(20000) * 0.5
+    clouds["wide"] = wide
+    far = pts[:15000].copy()
+    far['x'][::500] += 50.0
+    far['z'][250::500] -= 30.0
+    clouds["far"] = far
+    bad = pts[:15000].copy()
+    bad['x'][100] = np.nan; bad['y'][5000] = np.inf
+    clouds["bad"] = bad
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, p in clouds.items():
+            np.save(os.path.join(tmp, name + ".npy"), p)
+        code = (
+            "import sys, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "import cwipc_util_amd as cw\n"
+            "for name in %r:\n"
+            "    pts = np.load(%r %% name)\n"
+            "    for k in (16, 5, 24):\n"
+            "        d, _ = cw.cwipc_hip_knn_mean_dist(cw.cwipc_from_numpy_array(pts, 1), k, 1.0)\n"
+            "        np.save(%r %% (name, k, sys.argv[1]), d)\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sorted(clouds), os.path.join(tmp, "%s.npy"), os.path.join(tmp, "d_%s_%d_%s.npy"))
+        for layout in ("0", "1"):
+            subprocess.run([sys.executable, "-c", code, layout], check=True, env=dict(os.environ, CWIPC_SOR_SPARSE=layout), timeout=600)
+        for name, p in clouds.items():
+            for k in (16, 5, 24):
+                dense, sparse = (np.load(os.path.join(tmp, "d_%s_%d_%s.npy" % (name, k, l))) for l in ("0", "1"))
+                fin = np.isfinite(p['x']) & np.isfinite(p['y']) & np.isfinite(p['z'])
+                assert (dense[fin].view(np.uint32) == sparse[fin].view(np.uint32)).all(), (name, k)
+                if name != "bad":
+                    want = oracle.knn_mean_dist(p, k)
+                    assert (sparse.view(np.uint32) == want.view(np.uint32)).all(), (name, k)
+
+
 def test_downsample_grid_overflow_is_an_error(gpu, oracle):
     """pcl::VoxelGrid refuses grids of more than 2^31 cells; the reference then returns NULL."""
     pts = oracle.empty(2)
