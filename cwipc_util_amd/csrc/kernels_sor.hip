@@ -44,6 +44,67 @@ struct Grid {
 // grid are still one contiguous run of the sorted points, whatever segments are missing in between.
 constexpr int SEG = 16, SEG_SHIFT = 4;
 
+// The dense layout's grid is decided ON THE DEVICE (small and medium clouds: a tile of a frame is filtered in ~0.1 ms, and two
+// host round trips -- for the bounding box, for the occupancy census -- were a third of that): the kernels read the grid
+// from this block, which two one-wave kernels fill in.
+struct GridMeta {
+    Grid g;
+    double ext[3], maxext;
+    uint32_t occ;      // occupied cells of the first count (census)
+    uint32_t refine;   // 1: the grid was coarsened after the census, the cells are counted again
+};
+__device__ __forceinline__ void grid_dims(Grid &g, const double ext[3], double h) {
+    for (int a = 0; a < 3; a++) g.dim[a] = (int)floor(ext[a] / h) + 1;
+    g.h = h;
+    g.inv_h = 1.0 / h;
+    g.nsegx = (g.dim[0] + SEG - 1) / SEG;
+}
+__device__ __forceinline__ size_t grid_cells(const Grid &g) { return (size_t)g.dim[0] * (size_t)g.dim[1] * (size_t)g.dim[2]; }
+
+// one wave: the cloud's box from the partial boxes, then the finest grid of at most cap_cells cells
+__global__ void __launch_bounds__(64) grid_setup_kernel(const float *__restrict__ partial, unsigned nb, size_t cap_cells, GridMeta *__restrict__ m) {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (unsigned b = threadIdx.x; b < nb; b += 64)
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], partial[b * 6 + a]); hi[a] = fmaxf(hi[a], partial[b * 6 + 3 + a]); }
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64)); hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64)); }
+    if (threadIdx.x != 0) return;
+    Grid g;
+    double ext[3], maxext = 0;
+    for (int a = 0; a < 3; a++) {
+        g.mn[a] = lo[a] == FLT_MAX ? 0.f : lo[a];
+        ext[a] = (double)hi[a] - (double)lo[a];
+        if (!(ext[a] >= 0)) ext[a] = 0;   // no finite point
+        if (ext[a] > maxext) maxext = ext[a];
+    }
+    if (!(maxext > 0)) maxext = 1.0;
+    double h = maxext / 1024.0;
+    grid_dims(g, ext, h);
+    while (grid_cells(g) > cap_cells) { h *= 1.25; grid_dims(g, ext, h); }
+    m->g = g;
+    for (int a = 0; a < 3; a++) m->ext[a] = ext[a];
+    m->maxext = maxext;
+    m->occ = 0;
+    m->refine = 0;
+}
+
+// one lane: coarsen so that an occupied cell holds about `target` points (surface-like data: points per cell grow with h^2)
+__global__ void grid_refine_kernel(GridMeta *__restrict__ m, size_t n, double target) {
+    const double ppc = (double)n / (double)(m->occ ? m->occ : 1u);
+    if (!(ppc < target)) return;
+    double h = m->g.h * sqrt(target / ppc);
+    if (h > m->maxext) h = m->maxext;
+    Grid g = m->g;
+    grid_dims(g, m->ext, h);
+    m->g = g;
+    m->refine = 1;
+}
+
+__global__ void __launch_bounds__(BLK) zero_if_refined_kernel(uint32_t *__restrict__ words, size_t nwords, const GridMeta *__restrict__ m) {
+    if (!m->refine) return;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nwords; i += (size_t)gridDim.x * BLK) words[i] = 0;
+}
+
 __device__ __forceinline__ int cell_coord(const Grid &g, float v, int a) {
     int c = (int)floor(((double)v - (double)g.mn[a]) * g.inv_h);
     c = c < 0 ? 0 : c;
@@ -99,8 +160,11 @@ __device__ __forceinline__ WaveRun wave_run(uint32_t c, bool active) {
     return r;
 }
 
-__global__ void __launch_bounds__(BLK) cell_count_kernel(Grid g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
-                                                        size_t n, uint32_t *__restrict__ counts, uint32_t *__restrict__ cell_id) {
+__global__ void __launch_bounds__(BLK) cell_count_kernel(Grid gv, const GridMeta *__restrict__ gm, int second_count, const float *__restrict__ x,
+                                                        const float *__restrict__ y, const float *__restrict__ z, size_t n, uint32_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ cell_id) {
+    if (gm && second_count && !gm->refine) return;   // the census's grid stands: its counts do too
+    const Grid g = gm ? gm->g : gv;
     for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
         const size_t i = base + threadIdx.x;
         const bool active = i < n;
@@ -224,8 +288,10 @@ __global__ void __launch_bounds__(BLK) seg_count_kernel(const uint32_t *__restri
 // best[] lives in LDS, one column per lane: best[j * QB + lane].
 constexpr int QB = 128;
 
-__global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid g, const float4 *__restrict__ sorted, size_t n, const uint32_t *__restrict__ cell_start,
-                                                          const uint32_t *__restrict__ cell_count, int k, float *__restrict__ dist_out) {
+__global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
+                                                          const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_count, int k,
+                                                          float *__restrict__ dist_out) {
+    const Grid g = gm ? gm->g : gv;
     extern __shared__ float best_all[];
     float *best = best_all + threadIdx.x;
     const int want = k + 1;
@@ -299,8 +365,10 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid g, const float4 
 // SPARSE: cell_start is indexed by the cells that exist (one entry more than there are cells: the end), cell_count is the
 // segment table (seg_pack_kernel).
 template <int KCAP, bool SPARSE>
-__global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid g, const float4 *__restrict__ sorted, size_t n, const uint32_t *__restrict__ cell_start,
-                                                              const uint32_t *__restrict__ cell_count, int k, float *__restrict__ dist_out) {
+__global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
+                                                              const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_count, int k,
+                                                              float *__restrict__ dist_out) {
+    const Grid g = gm ? gm->g : gv;
     const int want = k + 1, pad = KCAP - want;
     size_t qi = (size_t)blockIdx.x * QB + threadIdx.x;
     if (qi >= n) return;
@@ -462,6 +530,74 @@ static inline unsigned grid_for(size_t n) {
     return (unsigned)g;
 }
 
+// The dense layout, driven from the device: box -> grid -> census -> (coarser grid, second count) -> counting sort -> k-NN,
+// sixteen launches and no wait (the caller has one further down, behind the compaction).  Arrays are sized for the largest
+// grid the rules allow (a few cells per point), whatever the kernels then decide.
+bool sor_dense_on_device(const DeviceSoA &src, int k, float *dev_dist, float *partial, unsigned nb, ThreadCtx &c) {
+    const size_t n = src.npoints;
+    static const size_t cells_per_point = []() { const char *e = getenv("CWIPC_SOR_CELLS_PER_POINT"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)8; }();   // tuning knob
+    const size_t cap = std::min<size_t>(MAX_CELLS, std::max<size_t>((size_t)1 << 16, cells_per_point * n));
+    double target = (double)(k + 1) / 2.0;
+    if (const char *t = getenv("CWIPC_SOR_CELL_TARGET")) target = (double)(k + 1) * atof(t);   // tuning knob: points per occupied cell / (k + 1)
+    GridMeta *meta = (GridMeta *)pool_alloc(sizeof(GridMeta));
+    uint32_t *counts = (uint32_t *)pool_alloc(cap * sizeof(uint32_t));
+    uint32_t *starts = (uint32_t *)pool_alloc(cap * sizeof(uint32_t));
+    uint32_t *cursor = (uint32_t *)pool_alloc(cap * sizeof(uint32_t));
+    uint32_t *cell_id = (uint32_t *)pool_alloc(n * sizeof(uint32_t));
+    float4 *sorted = (float4 *)pool_alloc(n * sizeof(float4));
+    void *scan_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, counts, starts, 0u, cap, rocprim::plus<uint32_t>(), c.stream);
+    if (e == hipSuccess) scan_tmp = pool_alloc(tmp_bytes ? tmp_bytes : 256);
+    auto give_back = [&](bool later) {
+        void *all[] = {partial, meta, counts, starts, cursor, cell_id, sorted, scan_tmp};
+        for (void *b : all) { if (later) c.free_later(b); else pool_free(b); }
+    };
+    if (e != hipSuccess || !meta || !counts || !starts || !cursor || !cell_id || !sorted || !scan_tmp) {
+        (void)c.sync();
+        give_back(false);
+        return hip_failed(e != hipSuccess ? e : hipErrorOutOfMemory, "sor workspace", __FILE__, __LINE__);
+    }
+    const Grid unused{};
+    const unsigned cap_grid = std::min(1024u, grid_for(cap / 4 + 1));
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, c.stream, partial, nb, cap, meta);
+    bool ok = hipMemsetAsync(counts, 0, cap * sizeof(uint32_t), c.stream) == hipSuccess &&
+              hipMemsetAsync(cursor, 0, cap * sizeof(uint32_t), c.stream) == hipSuccess;
+    if (ok) {
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, unused, meta, 0, src.x(), src.y(), src.z(), n, counts, cell_id);
+        CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(cap_grid), dim3(BLK), 0, c.stream, counts, cap, &meta->occ);
+        hipLaunchKernelGGL(grid_refine_kernel, dim3(1), dim3(1), 0, c.stream, meta, n, target);
+        hipLaunchKernelGGL(zero_if_refined_kernel, dim3(cap_grid), dim3(BLK), 0, c.stream, counts, cap, meta);
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, unused, meta, 1, src.x(), src.y(), src.z(), n, counts, cell_id);
+        if (profiling_enabled()) profile_begin("sor_exclusive_scan", c.stream);
+        e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, counts, starts, 0u, cap, rocprim::plus<uint32_t>(), c.stream);
+        if (profiling_enabled()) profile_end(c.stream);
+        ok = e == hipSuccess;
+    }
+    if (ok) {
+        CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts, cursor,
+                  sorted);
+        const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
+        const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
+        if (k + 1 <= 17) {
+            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
+        } else if (k + 1 <= 33) {
+            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
+        } else {
+            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
+        }
+    }
+    ok = hipGetLastError() == hipSuccess && ok;
+    if (!ok) {
+        hip_failed(e != hipSuccess ? e : hipGetLastError(), "sor k-NN", __FILE__, __LINE__);
+        (void)c.sync();
+        give_back(false);
+        return false;
+    }
+    give_back(true);
+    return true;
+}
+
 }  // namespace
 
 bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
@@ -483,6 +619,10 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     float *partial = (float *)pool_alloc((size_t)nb * 6 * sizeof(float));
     if (!partial) return false;
     CW_LAUNCH("sor_bbox", bbox_kernel, dim3(nb), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, partial);
+    static const int sparse_knob = []() { const char *e = getenv("CWIPC_SOR_SPARSE"); return e ? atoi(e) : -1; }();   // test knob: 1 always, 0 never
+    const bool sparse = (sparse_knob == 1 || (sparse_knob != 0 && n >= ((size_t)1 << 20))) && k + 1 <= 33;
+    static const bool host_grid = []() { const char *e = getenv("CWIPC_SOR_HOST_GRID"); return e && atoi(e) != 0; }();   // test knob: the dense layout decided by the host
+    if (!sparse && !host_grid) return sor_dense_on_device(src, k, dev_dist, partial, nb, c);
     float *hpart = (float *)c.staging((size_t)nb * 6 * sizeof(float));
     bool ok = hpart && hipMemcpyAsync(hpart, partial, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
     ok = c.sync() && ok;
@@ -515,8 +655,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     };
     auto cells_of = [](const Grid &g) { return (size_t)g.dim[0] * (size_t)g.dim[1] * (size_t)g.dim[2]; };
     // ---- big clouds: the sparse layout (segments of 16 cells, only those that hold points) ----
-    static const int sparse_knob = []() { const char *e = getenv("CWIPC_SOR_SPARSE"); return e ? atoi(e) : -1; }();   // test knob: 1 always, 0 never
-    if ((sparse_knob == 1 || (sparse_knob != 0 && n >= ((size_t)1 << 20))) && k + 1 <= 33) {
+    if (sparse) {
         static const size_t sparse_cpp = []() { const char *e = getenv("CWIPC_SOR_SPARSE_CELLS_PER_POINT"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)16; }();
         // cells of the (virtual) fine grid: a few dozen per point, and segment numbers must fit 27 bits
         const size_t budget = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)1 << 16, sparse_cpp * n));
@@ -601,9 +740,9 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
                       cursor, sorted);
             const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
             if (k + 1 <= 17) {
-                CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, true>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, info, k, dev_dist);
+                CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, true>), dim3(qgrid), dim3(QB), 0, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, info, k, dev_dist);
             } else {
-                CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, true>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, info, k, dev_dist);
+                CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, true>), dim3(qgrid), dim3(QB), 0, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, info, k, dev_dist);
             }
         }
         ok = hipGetLastError() == hipSuccess && ok;
@@ -635,7 +774,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess &&
          hipMemsetAsync(occ_dev, 0, sizeof(uint32_t), c.stream) == hipSuccess;
     if (ok) {
-        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, src.x(), src.y(), src.z(), n, counts, cell_id);
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, (const GridMeta *)nullptr, 0, src.x(), src.y(), src.z(), n, counts, cell_id);
         CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(std::min(1024u, grid_for(ncells / 4 + 1))), dim3(BLK), 0, c.stream, counts, ncells, occ_dev);
         ok = hipMemcpyAsync(c.host_words, occ_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
     }
@@ -650,7 +789,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         g = make_grid(h);
         ncells = cells_of(g);
         ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess;
-        if (ok) CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, src.x(), src.y(), src.z(), n, counts, cell_id);
+        if (ok) CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, (const GridMeta *)nullptr, 0, src.x(), src.y(), src.z(), n, counts, cell_id);
     }
 
     // 3. counting sort: exclusive scan of the counts, scatter
@@ -682,11 +821,11 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
         const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
         if (k + 1 <= 17) {
-            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, counts, k, dev_dist);
         } else if (k + 1 <= 33) {
-            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+            CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, counts, k, dev_dist);
         } else {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, sorted, n, starts, counts, k, dev_dist);
+            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, counts, k, dev_dist);
         }
     }
     // no wait here: every caller has one further down (the compaction, a copy to the host), and the
