@@ -220,9 +220,9 @@ _CWIPC_UTIL_EXPORT void _cwipc_log_emit(int level, const char *module, const cha
 _CWIPC_UTIL_EXPORT int cwipc_dangling_allocations(bool log);
 
 /* ---- constructors (reference api.h:632-709) ---- */
-_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_read(const char *filename, uint64_t timestamp, char **errorMessage, uint64_t apiVersion);               /* PLY: out of scope, fails with a message */
-_CWIPC_UTIL_EXPORT int cwipc_write(const char *filename, cwipc_pointcloud *pc, char **errorMessage);                                              /* PLY: out of scope */
-_CWIPC_UTIL_EXPORT int cwipc_write_ext(const char *filename, cwipc_pointcloud *pc, int flag, char **errorMessage);                                /* PLY: out of scope */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_read(const char *filename, uint64_t timestamp, char **errorMessage, uint64_t apiVersion);               /* PLY (x, y, z, rgba), ASCII or binary: csrc/ply.cpp */
+_CWIPC_UTIL_EXPORT int cwipc_write(const char *filename, cwipc_pointcloud *pc, char **errorMessage);                                              /* ASCII PLY in the layout PCL writes */
+_CWIPC_UTIL_EXPORT int cwipc_write_ext(const char *filename, cwipc_pointcloud *pc, int flag, char **errorMessage);                                /* flag & CWIPC_FLAG_BINARY: binary PLY */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_from_points(struct cwipc_point *points, size_t size, int npoint, uint64_t timestamp, char **errorMessage, uint64_t apiVersion);
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_from_packet(uint8_t *packet, size_t size, char **errorMessage, uint64_t apiVersion);
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_read_debugdump(const char *filename, char **errorMessage, uint64_t apiVersion);

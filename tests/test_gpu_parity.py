@@ -265,6 +265,38 @@ def test_simulatecams_golden(gpu):
     assert (soft['tile'] == hard).mean() > 0.5
 
 
+def test_native_downsample_app(gpu, oracle, synth, tmp_path):
+    """The reference's native tool and ctest (apps/cwipc_downsample: `cwipc_downsample 0.1 in.ply out.ply`) as a program of
+    our own linked against this library (tests/abi/downsample_app.cpp): PLY in, filter through the C ABI and the C++ virtuals,
+    PLY out (ASCII and binary), no objects left behind; the file it writes holds the oracle's result."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "cwipc_util_amd", "lib")
+    exe = str(tmp_path / "downsample_app")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi", "downsample_app.cpp"),
+                    "-o", exe, "-L" + libdir, "-lcwipc_util", "-Wl,-rpath," + libdir], check=True)
+    pts, cs = synth(100000, 0.4)
+    src = str(tmp_path / "in.ply")
+    gpu.cwipc_write(src, make_cloud(gpu, pts, cs, 1), True)
+    for cell, flavour in ((0.1, []), (0.02, ["binary"]), (-0.05, [])):
+        dst = str(tmp_path / ("out_%s.ply" % cell))
+        run = subprocess.run([exe, str(cell), src, dst] + flavour, capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stderr
+        got = gpu.cwipc_read(dst, 9).get_numpy_array()
+        exp, _ = oracle.downsample(pts, 0.0, cell)   # (a PLY file carries no cellsize: the tool's input has none)
+        assert len(got) == len(exp), (cell, len(got), len(exp))
+        for f in ('r', 'g', 'b', 'tile'):
+            assert (got[f] == exp[f]).all(), (cell, f)
+        tol = XYZ_TOL if flavour else 2e-5   # ASCII files hold 8 significant digits
+        for f in ('x', 'y', 'z'):
+            assert np.abs(got[f].astype(np.float64) - exp[f]).max() <= tol, (cell, f)
+    assert subprocess.run([exe, "0.1", str(tmp_path / "missing.ply"), str(tmp_path / "x.ply")], capture_output=True).returncode == 1
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
 def test_tiles_used(gpu, oracle, synth):
     pts, cs = synth(100000)
     assert gpu.get_tiles_used(make_cloud(gpu, pts, cs)) == oracle.tiles_used(pts) == [1, 2]
