@@ -7,26 +7,32 @@
 Workload (BASELINE.json configs[1]): cwipc_synthetic(npoints=10 000 000) -> N = 9 998 244 points
 (159 971 904 B), device-resident; one step = one cwipc_downsample(pc, +0.01) through the C-ABI
 (octree-split path, the reference's default).  Steps rotate over 4 distinct device copies
-(640 MB > the 256 MB Infinity Cache) so every step reads cold HBM.
+(640 MB > the 256 MB Infinity Cache) so every step reads cold HBM.  In a stream of calls the library hands a
+result out while its kernels still run (it settles on first use); the timed region ends with a wait for everything.
 
 N > 1 (weak scaling): every rank holds one camera tile of the same size (tile mask 1 << rank),
 runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join -- the path's one
 exchange step: RCCL inside the library (cwipc_hip_comm_join, one C call per frame; CWIPC_BENCH_EXCHANGE=torch selects
 the same protocol on torch.distributed, cwipc_util_amd.multigpu, which is also what the bench falls back to, on all
-ranks together, should the library's exchange fail its preflight against it).  Frames stream: the join of frame i runs on a
-worker thread while the main thread downsamples frame i + 1 (at most two frames in flight; all joins are
-complete when the timed region ends).  For N > 1 the library is told to leave 24 compute units out of the
-voxel kernel's persistent grid (CWIPC_SPARE_CUS, unless already set), so that the join's small kernels do not
-wait for a whole downsample.  Rehearsal knobs: CWIPC_BENCH_BACKEND=gloo (several ranks on one GPU, exchange
-staged through the host), CWIPC_BENCH_FORCE_JOIN=1 (N = 1 with a one-rank RCCL group: the whole N > 1 step
-but the wire), CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other), CWIPC_BENCH_JOIN_ASYNC=0 (the
-worker waits for every frame's collective before it takes the next frame).
+ranks together, should the library's exchange fail its preflight against it -- a comparison on a real frame, under a
+time limit).  Frames stream: the join of frame i runs on a worker thread while the main thread downsamples frame
+i + 1 (at most two frames in flight; all joins are complete when the timed region ends).  For N > 1 the library is
+told to leave 24 compute units out of the voxel kernel's persistent grid (CWIPC_SPARE_CUS, unless already set), so that
+the join's kernels do not wait for a whole downsample.  Rehearsal knobs: CWIPC_BENCH_BACKEND=gloo (several ranks on one
+GPU, exchange staged through the host), CWIPC_BENCH_FORCE_JOIN=1 (N = 1 with a one-rank RCCL group: the whole N > 1
+step but the wire), CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other), CWIPC_BENCH_JOIN_ASYNC=0 (torch
+exchange: the worker waits for every frame's collective before it takes the next frame).
 
-One JSON line on rank 0.  `value` = points filtered by all ranks / wall time of the K timed steps
-(max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel
-(16 B per input point + 16 B per output point) / its mean launch duration, measured with hipEvents
-on the library's stream during a second pass over the same steps.  `cpu_baseline` = the CPU oracle
-(a single-threaded C restatement of the PCL algorithm, NOT PCL) on the same cloud, rank 0, N = 1 only.
+One JSON line on rank 0, the only thing written to stdout.  `value` = points filtered by all ranks / wall time of the K
+timed steps (max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel (16 B per
+input point + 16 B per output point, all N points in one launch) / its mean launch duration, measured with hipEvents on
+the library's stream during a second pass over the same steps (each call waited for, so the kernel runs alone);
+`traffic` = HBM bytes per launch from the newest committed PMC passes (profiles/rNN_traffic.json).  `cpu_baseline` = the
+CPU oracle (a single-threaded C restatement of the PCL algorithm, NOT PCL) on the same cloud, rank 0, N = 1 only: one
+core, and (`all_cores`) every core of the host running one cloud each.  Sub-records in the same line: `config4` =
+BASELINE configs[3], the 8 x 2 M-tile capture (tilefilter -> downsample per tile, n-ary join, join across ranks), tile t
+on rank t mod N, strong scaling; `config3` = BASELINE configs[2], outlier removal of the 10 M cloud (N = 1 only), with its
+own roofline fraction over all kernels of a call.
 """
 from __future__ import annotations
 
