@@ -715,6 +715,42 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
             assert same(got, np.load(os.path.join(tmp, "out_%s.npy" % c))), c
 
 
+@pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0"])
+def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
+    """Every environment knob of the shipped library selects another way to the same result: a
+    process with the knob set must produce, bit for bit, what this process produces -- a stream of downsample calls (the
+    early return), a stream on a shuffled cloud (the partition pass), outlier removal (where the grid is decided), the
+    synthetic source (where it is generated)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pts, cs = synth(200000, 0.1)
+    np.save(str(tmp_path / "pts.npy"), pts)
+    code = (
+        "import sys, struct, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import cwipc_util_amd as cw\n"
+        "pts = np.load(%r); out = {}\n"
+        "pc = cw.cwipc_from_numpy_array(pts, 1); pc._set_cellsize(%r)\n"
+        "for i in range(6): out['down%%d' %% i] = cw.cwipc_downsample(pc, 0.01).get_numpy_array()\n"
+        "perm = pts[np.random.default_rng(3).permutation(len(pts))]\n"
+        "pp = cw.cwipc_from_numpy_array(perm, 1); pp._set_cellsize(%r)\n"
+        "for i in range(6): out['perm%%d' %% i] = cw.cwipc_downsample(pp, 0.01).get_numpy_array()\n"
+        "out['sor'] = cw.cwipc_remove_outliers(cw.cwipc_from_numpy_array(pts[:50000], 1), 16, 1.0, False).get_numpy_array()\n"
+        "src = cw.cwipc_synthetic(0, 100000); src.start(); b = bytearray(4)\n"
+        "assert src.auxiliary_operation('amd-fixangle', struct.pack('f', 0.5), b)\n"
+        "out['synth'] = src.get().get_numpy_array(); src.stop()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (root, str(tmp_path / "pts.npy"), cs, cs)
+    ours, theirs = str(tmp_path / "default.npz"), str(tmp_path / "knob.npz")
+    name, value = knob.split("=")
+    subprocess.run([sys.executable, "-c", code, ours], check=True, timeout=600, env={k: v for k, v in os.environ.items() if k != name})
+    subprocess.run([sys.executable, "-c", code, theirs], check=True, timeout=600, env=dict(os.environ, **{name: value}))
+    a, b = np.load(ours), np.load(theirs)
+    assert sorted(a.keys()) == sorted(b.keys())
+    for key in a.keys():
+        assert same(a[key], b[key]), (knob, key)
+
+
 def test_sor_sparse_and_dense_grid_layouts_agree(gpu, oracle, synth):
     """The k-NN grid has two layouts: dense (small clouds) and segments of 16 cells that exist only where points are (big
     clouds, kernels_sor.hip).  d_i is a property of the cloud, not of the search structure: both layouts, forced through
