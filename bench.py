@@ -145,8 +145,7 @@ def cpu_baseline(points: np.ndarray, pc_cellsize: float, budget_s: float = 10.0)
 def bench_config4(cwipc, rank: int, world: int, steps: int, warmup: int, fence, join_across_ranks):
     """BASELINE configs[3]: the 8-tile capture (8 x synthetic(2 000 000), camera mask 1 << i, rotated i x 45 degrees),
     tile t on rank t mod world; per tile tilefilter(1 << t) -> downsample(0.01); the local results joined (n-ary join),
-    then the all-gatherv join across ranks.  N = 1 runs all eight tiles one after the other.  Strong scaling: the job is
-    the same 8 tiles whatever N is."""
+    then the all-gatherv join across ranks.  Strong scaling: the job is the same 8 tiles whatever N is."""
     from cwipc_util_amd.capture import capture_tile, per_tile_chain
     from cwipc_util_amd.multigpu import tiles_of_rank
     NT, NP = 8, 2_000_000
@@ -158,8 +157,24 @@ def bench_config4(cwipc, rank: int, world: int, steps: int, warmup: int, fence, 
         tiles.append((t, pc))
     n_tile = tiles[0][1].count() if tiles else 0
 
+    # The tiles of a frame are filtered on a few threads of this rank, as the reference's per-tile decoders are threads
+    # (net/source_synchronizer.py:128-149); every thread has its own streams and workspaces in the library, so the small kernels
+    # of different tiles overlap.  CWIPC_BENCH_TILE_THREADS=1 filters them one after the other.
+    nthreads = max(1, min(int(os.environ.get("CWIPC_BENCH_TILE_THREADS", "4")), len(tiles)))
+    pool = None
+    if nthreads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=nthreads)
+
+    def some_tiles(k):
+        return [(i, per_tile_chain(pc, t, CELLSIZE)) for i, (t, pc) in enumerate(tiles) if i % nthreads == k]
+
     def frame():
-        outs = [per_tile_chain(pc, t, CELLSIZE) for t, pc in tiles]
+        if pool is None:
+            outs = [per_tile_chain(pc, t, CELLSIZE) for t, pc in tiles]
+        else:
+            done = sorted((item for part in pool.map(some_tiles, range(nthreads)) for item in part), key=lambda item: item[0])
+            outs = [o for _, o in done]   # tile order = the reference's fold order
         local = cwipc.cwipc_join_multi(outs) if outs else None
         return join_across_ranks(local) if join_across_ranks is not None else local
 
@@ -171,7 +186,9 @@ def bench_config4(cwipc, rank: int, world: int, steps: int, warmup: int, fence, 
         fused = frame()
     fence()
     elapsed = time.perf_counter() - t0
-    return elapsed, n_tile, (fused.count() if fused is not None else 0), len(mine)
+    if pool is not None:
+        pool.shutdown()
+    return elapsed, n_tile, (fused.count() if fused is not None else 0), len(mine), nthreads
 
 
 def bench_config3(cwipc, pc, n: int, runs: int = 5):
@@ -437,7 +454,7 @@ def main() -> None:
     if not args.no_config4:
         if joiner is not None:
             joiner.drain()
-        c4_elapsed, c4_ntile, c4_fused, c4_mine = bench_config4(cwipc, rank, world, args.config4_steps, 3, fence,
+        c4_elapsed, c4_ntile, c4_fused, c4_mine, c4_threads = bench_config4(cwipc, rank, world, args.config4_steps, 3, fence,
                                                                 join_across_ranks if joining else None)
         if dist is not None:
             t = torch.tensor([c4_elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -450,7 +467,7 @@ def main() -> None:
             "value": 8 * c4_ntile * args.config4_steps / c4_elapsed / 1e6 if c4_ntile else None,
             "unit": "Mpoints/s", "scaling": "strong", "n_gpus": world, "steps": args.config4_steps,
             "ms_per_frame": c4_elapsed / args.config4_steps * 1e3, "points_per_tile": c4_ntile, "tiles_on_rank0": c4_mine,
-            "fused_points": c4_fused, "inputs_resident_in_hbm": True,
+            "fused_points": c4_fused, "inputs_resident_in_hbm": True, "tile_threads_per_rank": c4_threads,
         }
     config3 = None
     if world == 1 and not args.no_config3 and args.npoints == NPOINTS_ARG:
