@@ -455,6 +455,66 @@ def test_downsample_stream_of_permuted_frames_goes_through_the_partition_pass(gp
         assert "partition_scatter" in prof.kernels, sorted(prof.kernels)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_partition_pass_on_random_shuffled_clouds(gpu, oracle, seed):
+    """The partition pass on clouds it was not tuned on: several points per voxel, voxels scattered along a line tens of metres
+    long (the 16 x 16 x 16 window of coarse cells folds over many times: far-apart cells share a bucket), on a plane, or in
+    clusters with far outliers; random order; non-finite points in between.  A stream of calls, every call equal to the
+    oracle's walk over the same shuffled cloud, octree variant and plain grid."""
+    rng = np.random.default_rng(seed)
+    cell = float(rng.choice([0.01, 0.02, 0.005]))
+    shape = ["line", "plane", "clusters", "line"][seed - 1]
+    nvox = int(rng.integers(15000, 30000))
+    if shape == "line":
+        centres = np.stack([rng.random(nvox) * 6000 * cell, rng.random(nvox) * 20 * cell, rng.random(nvox) * 20 * cell], axis=1)
+    elif shape == "plane":
+        centres = np.stack([rng.random(nvox) * 600 * cell, rng.random(nvox) * 600 * cell, 3 * cell * np.sin(rng.random(nvox) * 6)], axis=1)
+    else:
+        blobs = rng.random((12, 3)) * 300 * cell
+        centres = blobs[rng.integers(0, 12, nvox)] + rng.normal(0, 12 * cell, (nvox, 3))
+        centres[::997] += 2000 * cell
+    per = int(rng.integers(5, 9))
+    # `per` points inside each chosen voxel (corners on the voxel lattice, so that they do share it)
+    corners = np.floor(centres / cell) * cell + round(float(rng.choice([0.0, -40.0, 7.3])) / cell) * cell
+    xyz = (np.repeat(corners, per, axis=0) + (0.05 + 0.9 * rng.random((nvox * per, 3))) * cell).astype(np.float32)
+    n = len(xyz)
+    pts = oracle.empty(n)
+    pts['x'], pts['y'], pts['z'] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts['r'], pts['g'], pts['b'] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n)
+    pts['tile'] = 1 << rng.integers(0, 8, n)
+    pts = pts[rng.permutation(n)]
+    for variant in (cell, -cell):
+        p = pts.copy()
+        if variant > 0:
+            bad = rng.integers(1, n, 20)
+            p['y'][bad] = np.nan
+        if variant < 0 and shape == "line":
+            continue   # (pcl::VoxelGrid refuses a grid of this extent at this cell size: the 2^31 rule; the octree path is the one for it)
+        pc = make_cloud(gpu, p, 0.0, 5)
+        try:
+            exp, _ = oracle.downsample(p, 0.0, variant)
+        except oracle.OracleError:   # the 2^31-cell rule of pcl::VoxelGrid: the reference returns NULL, and so does the library
+            with pytest.raises(gpu.CwipcError):
+                gpu.cwipc_downsample(pc, variant)
+            continue
+        assert n > 4 * len(exp)
+        for call in range(6):
+            got = gpu.cwipc_downsample(pc, variant).get_numpy_array()
+            assert len(got) == len(exp), (shape, variant, call, len(got), len(exp))
+            for f in ('r', 'g', 'b', 'tile'):
+                assert (got[f] == exp[f]).all(), (shape, variant, call, f)
+            scale = max(float(np.abs(p[f][np.isfinite(p[f])]).max()) for f in ('x', 'y', 'z'))
+            tol = max(XYZ_TOL, 4.0 * float(np.spacing(np.float32(scale))))
+            for f in ('x', 'y', 'z'):
+                assert np.abs(got[f].astype(np.float64) - exp[f]).max() <= tol, (shape, variant, call, f)
+    if os.environ.get("CWIPC_VOXEL_PARTITION") != "0":
+        pc = make_cloud(gpu, pts, 0.0, 5)
+        with gpu.cwipc_hip_profile() as prof:
+            for call in range(5):
+                gpu.cwipc_downsample(pc, cell)
+        assert "partition_scatter" in prof.kernels, (shape, sorted(prof.kernels))
+
+
 def test_downsample_shifted_and_rotated(gpu, oracle, synth):
     """Clouds away from the origin, negative coordinates, several octree growth steps in every direction."""
     pts, cs = synth(100000)
