@@ -253,10 +253,15 @@ def main() -> None:
 
     if cwipc.cwipc_hip_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the filter path has no CPU fallback")
-    # one rank per GPU; CWIPC_BENCH_BACKEND=gloo lets several ranks share a GPU (rehearsal of the N > 1 path on a
-    # one-GPU box: RCCL refuses two ranks on one device)
-    backend = os.environ.get("CWIPC_BENCH_BACKEND", "nccl")
-    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    # One rank per GPU.  torch.distributed only bootstraps (it carries the library's RCCL id), fences and sums the timing: its
+    # process group is gloo.  A torch NCCL process group in the process costs every step ~20 us whether it is used or not
+    # (measured on one GPU: 84 instead of 62 us per step with the join -- its watchdog threads and the HIP runtime), so one
+    # is made only if the bench has to fall back to the torch.distributed exchange.  When there are more ranks than GPUs
+    # (a rehearsal on a one-GPU box: RCCL refuses two ranks on one device) the ranks share GPUs and the exchange is the
+    # torch one, staged through the host.
+    backend = os.environ.get("CWIPC_BENCH_BACKEND", "gloo")
+    own_gpu = world <= torch.cuda.device_count()
+    device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     cwipc.cwipc_hip_set_device(device_index)
     dist = None
@@ -300,8 +305,13 @@ def main() -> None:
         # "library": RCCL inside libcwipc_util.so, one C call per frame (cwipc_hip_comm_join); "torch": the same protocol on
         # torch.distributed (multigpu.SlotExchange).  The library's exchange is checked against the other on a real frame first
         # and all ranks fall back together if any of them disagrees.
-        exchange = os.environ.get("CWIPC_BENCH_EXCHANGE", "library" if backend == "nccl" else "torch")
+        exchange = os.environ.get("CWIPC_BENCH_EXCHANGE", "library" if own_gpu else "torch")
         abandon_at_exit = False
+        torch_group = [None]   # the group the torch exchange runs on: the default one, or an RCCL group made for it
+
+        def use_rccl_for_torch_exchange():
+            if backend != "nccl" and own_gpu and torch_group[0] is None:
+                torch_group[0] = dist.new_group(backend="nccl")   # collective: every rank comes here together
         if exchange == "library":
             # the preflight runs on a thread of its own with a time limit: two ranks on RCCL have never run where this was
             # written (one GPU), and a bench that hangs measures nothing.  A rank whose preflight does not come back leaves
@@ -330,16 +340,22 @@ def main() -> None:
                 abandon_at_exit = True
             good, why = verdict.get("good", False), verdict.get("why", "")
             # (second word: does any rank leave a stuck thread behind?  Then every rank ends with os._exit, none waits for another)
-            flag = torch.tensor([1 if good else 0, 0 if abandon_at_exit else 1], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([1 if good else 0, 0 if abandon_at_exit else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             abandon_at_exit = int(flag[1].item()) == 0
             if int(flag[0].item()) == 0:
                 exchange, exchange_note = "torch", "library exchange failed its preflight on some rank" + (f" (here: {why})" if why else "")
                 print(f"[rank {rank}] {exchange_note}", file=sys.stderr)
+        if exchange == "torch":
+            use_rccl_for_torch_exchange()
 
         def join_across_ranks(pc):
-            return multigpu.join_across_ranks(pc, exchange=exchange)
-    if pipelined:
+            return multigpu.join_across_ranks(pc, group=torch_group[0], exchange=exchange) if exchange == "torch" else multigpu.join_across_ranks(pc, exchange=exchange)
+    # the library's exchange pipelines inside the library (cwipc_hip_comm_submit: a thread of the communicator does the waiting,
+    # no Python thread, no interpreter lock on the per-frame path); the torch exchange needs the worker thread below
+    lib_comm = multigpu.library_comm() if (joining and pipelined and exchange == "library") else None
+    last_fused = [None]
+    if pipelined and lib_comm is None:
         import queue
         import threading
 
@@ -358,7 +374,7 @@ def main() -> None:
 
             def run(self):
                 torch.cuda.set_device(device_index)
-                pipe = JoinPipeline() if join_async else None
+                pipe = JoinPipeline(torch_group[0]) if join_async else None
                 self.idle = self.busy = 0.0
                 while True:
                     t_wait = time.perf_counter()
@@ -395,6 +411,9 @@ def main() -> None:
 
     def step(i: int):
         out = cwipc.cwipc_downsample(clouds[i % NCOPIES], CELLSIZE)
+        if lib_comm is not None:
+            last_fused[0] = lib_comm.submit(out)   # returns at once; frames are exchanged in this order
+            return out
         if joiner is not None:
             t_put = time.perf_counter()
             joiner.todo.put(out)
@@ -405,6 +424,8 @@ def main() -> None:
         return out
 
     def fence():
+        if lib_comm is not None and last_fused[0] is not None:
+            last_fused[0].count()   # settles: this frame's exchange, and every earlier one's, has been issued
         if joiner is not None:
             joiner.drain()
         cwipc.util.cwipc_util_dll_load().cwipc_hip_synchronize()
@@ -434,7 +455,7 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    fused_points = (joiner.drain() if joiner is not None else out).count()
+    fused_points = (last_fused[0] if lib_comm is not None else joiner.drain() if joiner is not None else out).count()
 
     # ---- second pass over the same steps with per-kernel hipEvent timing ----
     with cwipc.cwipc_hip_profile() as prof:
@@ -512,6 +533,10 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": algorithmic_bytes,
                 "kernel_ms_avg": dom_ms,
                 "all_kernels_ms_per_step": all_ms,
+                # in a stream of calls consecutive accumulate kernels overlap (each leaves one CU per XCD free for the next):
+                # what the chip sustains per call is the algorithmic traffic over the wall time of a step
+                "achieved_pipelined": algorithmic_bytes / (elapsed / args.steps) / 1e9,
+                "frac_pipelined": algorithmic_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
                 "achieved_all_kernels": algorithmic_bytes / (all_ms * 1e-3) / 1e9,
                 "frac_all_kernels": algorithmic_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },

@@ -19,7 +19,10 @@
 
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <thread>
 
 namespace cwipc_amd {
 
@@ -49,6 +52,42 @@ bool nccl_failed(ncclResult_t r, const char *what, char **errorMessage) {
 
 using namespace cwipc_amd;
 
+namespace {
+
+// The fused cloud of a frame handed out before the exchange has happened (cwipc_hip_comm_submit): the communicator's own
+// thread fills it in; the cloud that holds it settles on first use.
+struct PendingJoin : cwipc_amd::DeferredResult {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    std::shared_ptr<cwipc_amd::DeviceSoA> planes;   // nullptr: the exchange failed on this rank (logged)
+    uint64_t timestamp = 0;
+    float cellsize = 0;
+    void fulfil(std::shared_ptr<cwipc_amd::DeviceSoA> p, uint64_t ts, float cs) {
+        { std::lock_guard<std::mutex> g(m); planes = std::move(p); timestamp = ts; cellsize = cs; done = true; }
+        cv.notify_all();
+    }
+    std::shared_ptr<cwipc_amd::DeviceSoA> settle() override {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return done; });
+        return planes;
+    }
+    bool late_metadata(uint64_t *ts, float *cs) override {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return done; });
+        *ts = timestamp; *cs = cellsize;
+        return true;
+    }
+};
+
+struct JoinJob {
+    cwipc_amd::cwipc_hip_pointcloud::Snapshot input;   // has_data false + no planes: no tile this frame
+    bool has_cloud = false, bad_input = false, loopback = false, stop = false;
+    std::shared_ptr<PendingJoin> result;
+};
+
+}  // namespace
+
 struct cwipc_hip_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
@@ -57,6 +96,12 @@ struct cwipc_hip_comm {
     FrameMeta *meta_dev = nullptr;      // the same layout in device memory
     std::mutex lock;                    // one frame at a time per communicator (collectives must be issued in one order)
     unsigned long long frames = 0;
+    // cwipc_hip_comm_submit: frames wait here for the communicator's thread, which takes them in the order they came
+    std::mutex queue_lock;
+    std::condition_variable queue_cv;
+    std::deque<JoinJob> queue;
+    std::thread worker;
+    bool worker_running = false;
 };
 
 static_assert(CWIPC_HIP_COMM_ID_BYTES == sizeof(ncclUniqueId), "CWIPC_HIP_COMM_ID_BYTES is RCCL's ncclUniqueId");
@@ -110,6 +155,12 @@ extern "C" cwipc_hip_comm *cwipc_hip_comm_create(const void *id, int rank, int n
 
 extern "C" void cwipc_hip_comm_free(cwipc_hip_comm *cm) {
     if (cm == nullptr) return;
+    if (cm->worker_running) {   // frames still queued are exchanged first (the other ranks count on them)
+        { std::lock_guard<std::mutex> g(cm->queue_lock); JoinJob stop; stop.stop = true; cm->queue.push_back(std::move(stop)); }
+        cm->queue_cv.notify_all();
+        cm->worker.join();
+        cm->worker_running = false;
+    }
     if (cm->stream) (void)hipStreamSynchronize(cm->stream);
     if (cm->comm) (void)ncclCommDestroy(cm->comm);
     if (cm->stream) (void)hipStreamDestroy(cm->stream);
@@ -121,36 +172,31 @@ extern "C" void cwipc_hip_comm_free(cwipc_hip_comm *cm) {
 extern "C" int cwipc_hip_comm_rank(cwipc_hip_comm *cm) { return cm ? cm->rank : -1; }
 extern "C" int cwipc_hip_comm_nranks(cwipc_hip_comm *cm) { return cm ? cm->nranks : -1; }
 
-extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_pointcloud *pc, int flags) {
+namespace {
+
+struct JoinOutcome {
+    std::shared_ptr<DeviceSoA> planes;   // nullptr: failed (logged)
+    uint64_t timestamp = 0;
+    float cellsize = 0;
+};
+
+// One frame's exchange, once this rank's part is known: `src` are its planes (nullptr: no tile this frame, or a tile that
+// could not be read -- bad_input -- which the other ranks see as "no tile" while this rank's call fails).  The caller holds
+// cm->lock.
+JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint64_t src_ts, float src_cs, bool bad_input, bool loopback) {
     const char *who = "cwipc_hip_comm_join";
-    if (cm == nullptr) return nullptr;
-    const bool loopback = (flags & CWIPC_HIP_JOIN_LOOPBACK) != 0;
-    std::lock_guard<std::mutex> guard(cm->lock);
+    JoinOutcome none;
     ThreadCtx &c = tctx();
-    if (!c.ensure()) return nullptr;
+    if (!c.ensure()) return none;
     if (current_device() != cm->device) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "the communicator was made for another device");
-        return nullptr;
+        return none;
     }
-
-    // this rank's part.  A cloud that cannot be read counts as "no tile this frame" AFTER the exchange (the other ranks are
-    // already on their way into the collective: every rank must take part in every frame), and the call then fails here.
-    std::unique_ptr<cwipc_hip_pointcloud> keep;
-    std::shared_ptr<DeviceSoA> src;
-    bool bad_input = false;
-    if (pc != nullptr) {
-        src = [&]() -> std::shared_ptr<DeviceSoA> {
-            cwipc_hip_pointcloud *ours = as_ours(pc);
-            if (!ours) { keep = import_foreign(pc); ours = keep.get(); }
-            if (!ours || !ours->has_data()) return nullptr;
-            return ours->device_points();
-        }();
-        if (!src || src->npoints >= ((size_t)1 << 32)) { bad_input = true; src = nullptr; }
-    }
+    if (src && src->npoints >= ((size_t)1 << 32)) { bad_input = true; src = nullptr; }
     FrameMeta mine{};
     if (src) {
-        const float cs = pc->cellsize();
-        const uint64_t ts = pc->timestamp();
+        const float cs = src_cs;
+        const uint64_t ts = src_ts;
         mine.count = (uint32_t)src->npoints;
         mine.has_cloud = 1;
         memcpy(&mine.cellsize_bits, &cs, 4);
@@ -167,10 +213,10 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_point
         cm->meta_host[0] = mine;
         bool ok = hipMemcpyAsync(cm->meta_dev, cm->meta_host, sizeof(FrameMeta), hipMemcpyHostToDevice, cm->stream) == hipSuccess;
         ncclResult_t r = ok ? ncclAllGather(cm->meta_dev, cm->meta_dev + 1, sizeof(FrameMeta) / 4, ncclUint32, cm->comm, cm->stream) : ncclSuccess;
-        if (r != ncclSuccess) { nccl_failed(r, "ncclAllGather", nullptr); return nullptr; }
+        if (r != ncclSuccess) { nccl_failed(r, "ncclAllGather", nullptr); return none; }
         ok = ok && hipMemcpyAsync(all, cm->meta_dev + 1, sizeof(FrameMeta) * W, hipMemcpyDeviceToHost, cm->stream) == hipSuccess;
         ok = ok && hipStreamSynchronize(cm->stream) == hipSuccess;
-        if (!ok) { hip_failed(hipGetLastError(), who, __FILE__, __LINE__); return nullptr; }
+        if (!ok) { hip_failed(hipGetLastError(), who, __FILE__, __LINE__); return none; }
     }
     cm->frames++;
 
@@ -192,17 +238,18 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_point
     const size_t total = disp[W];
     if (total >= ((size_t)1 << 32)) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "the fused cloud would hold 2^32 points or more");
-        return nullptr;   // every rank sees the same counts and takes the same way out: nobody is left waiting
+        return none;   // every rank sees the same counts and takes the same way out: nobody is left waiting
     }
-    auto finish = [&](std::shared_ptr<DeviceSoA> planes) -> cwipc_pointcloud * {
+    auto finish = [&](std::shared_ptr<DeviceSoA> planes) -> JoinOutcome {
         if (bad_input) {
             cwipc_log(CWIPC_LOG_LEVEL_WARNING, who, "cannot read the point data of the argument (the other ranks got a frame without this tile)");
-            return nullptr;
+            return none;
         }
-        if (!planes) return nullptr;
-        auto *rv = new cwipc_hip_pointcloud();
-        rv->adopt_device(planes, ts_min, cs_min);
-        return rv;
+        JoinOutcome out;
+        out.planes = std::move(planes);
+        out.timestamp = ts_min;
+        out.cellsize = cs_min;
+        return out;
     };
     const size_t n_me = all[cm->rank].count;
     // all points are this rank's own: the result holds its planes, nothing moves (cwipc_hip_join_multi's rule)
@@ -213,7 +260,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_point
         // no result here, but the others will send: take what they send into nothing?  There is no such thing; a rank that
         // cannot allocate its result cannot stay in step, and saying so loudly is all that is left.
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "out of device memory for the fused cloud: this rank leaves the exchange");
-        return nullptr;
+        return none;
     }
     if (total == 0) return finish(dst);
 
@@ -241,7 +288,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_point
     if (r != ncclSuccess) {
         nccl_failed(r, "ncclSend/ncclRecv group", nullptr);
         (void)hipStreamSynchronize(cm->stream);   // `dst` goes back to the pool
-        return nullptr;
+        return none;
     }
     if (n_me && !loopback) {
         k::JoinPart part{src->x(), src->y(), src->z(), src->rgbt(), n_me, disp[cm->rank]};
@@ -249,10 +296,89 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_point
         if (hipError_t e = hipGetLastError(); e != hipSuccess) {
             hip_failed(e, who, __FILE__, __LINE__);
             (void)hipStreamSynchronize(cm->stream);
-            return nullptr;
+            return none;
         }
     }
     if (src) src->note_reader(cm->stream);   // the sends (and the copy) are still reading the input
     dst->mark_pending(cm->stream);
     return finish(dst);
+}
+
+// This rank's part of a frame as a snapshot: planes, or the pending result that will become them (see internal.hpp).
+JoinJob job_of(cwipc_pointcloud *pc, int flags) {
+    JoinJob job;
+    job.loopback = (flags & CWIPC_HIP_JOIN_LOOPBACK) != 0;
+    if (pc == nullptr) return job;
+    job.has_cloud = true;
+    std::unique_ptr<cwipc_hip_pointcloud> keep;
+    cwipc_hip_pointcloud *ours = as_ours(pc);
+    if (!ours) { keep = import_foreign(pc); ours = keep.get(); }
+    if (!ours || !ours->has_data()) { job.bad_input = true; return job; }
+    job.input = ours->snapshot();
+    if (!job.input.pending && !job.input.dev) job.bad_input = true;
+    return job;
+}
+
+JoinOutcome run_job(cwipc_hip_comm *cm, JoinJob &job) {
+    std::shared_ptr<DeviceSoA> src;
+    if (job.has_cloud && !job.bad_input) {
+        src = job.input.pending ? job.input.pending->settle() : job.input.dev;
+        if (!src) job.bad_input = true;   // (a filter that failed after its call had returned: logged there)
+    }
+    std::lock_guard<std::mutex> guard(cm->lock);
+    return join_frame(cm, src, job.input.timestamp, job.input.cellsize, job.bad_input, job.loopback);
+}
+
+void comm_worker(cwipc_hip_comm *cm) {
+    for (;;) {
+        JoinJob job;
+        {
+            std::unique_lock<std::mutex> g(cm->queue_lock);
+            cm->queue_cv.wait(g, [&] { return !cm->queue.empty(); });
+            job = std::move(cm->queue.front());
+            cm->queue.pop_front();
+        }
+        if (job.stop) return;
+        JoinOutcome out = run_job(cm, job);
+        job.result->fulfil(out.planes, out.timestamp, out.cellsize);
+    }
+}
+
+}  // namespace
+
+extern "C" cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *cm, cwipc_pointcloud *pc, int flags) {
+    if (cm == nullptr) return nullptr;
+    if (!device_available("cwipc_hip_comm_join")) return nullptr;
+    if (cm->worker_running) {
+        // frames submitted before this one are exchanged first: through the queue, and wait
+        cwipc_pointcloud *later = cwipc_hip_comm_submit(cm, pc, flags);
+        if (later == nullptr) return nullptr;
+        if (!as_ours(later)->has_device()) { later->free(); return nullptr; }   // (settles; a failed exchange leaves no planes)
+        return later;
+    }
+    JoinJob job = job_of(pc, flags);
+    JoinOutcome out = run_job(cm, job);
+    if (!out.planes) return nullptr;
+    auto *rv = new cwipc_hip_pointcloud();
+    rv->adopt_device(out.planes, out.timestamp, out.cellsize);
+    return rv;
+}
+
+extern "C" cwipc_pointcloud *cwipc_hip_comm_submit(cwipc_hip_comm *cm, cwipc_pointcloud *pc, int flags) {
+    if (cm == nullptr) return nullptr;
+    if (!device_available("cwipc_hip_comm_submit")) return nullptr;
+    JoinJob job = job_of(pc, flags);
+    job.result = std::make_shared<PendingJoin>();
+    auto *rv = new cwipc_hip_pointcloud();
+    rv->adopt_deferred(job.result, 0, 0.0f, true);
+    {
+        std::lock_guard<std::mutex> g(cm->queue_lock);
+        if (!cm->worker_running) {
+            cm->worker = std::thread(comm_worker, cm);
+            cm->worker_running = true;
+        }
+        cm->queue.push_back(std::move(job));
+    }
+    cm->queue_cv.notify_one();
+    return rv;
 }

@@ -198,6 +198,9 @@ struct DeferredResult {
     // Blocks until the result is there; nullptr = the filter failed (logged).  May be called from any thread, any
     // number of times.
     virtual std::shared_ptr<DeviceSoA> settle() = 0;
+    // Results whose timestamp and cellsize are themselves part of what is still being computed (the multi-GPU join: the
+    // minimum over the ranks' clouds) hand them over here, after settle(); false = they were known when the result was made.
+    virtual bool late_metadata(uint64_t *timestamp, float *cellsize) { (void)timestamp; (void)cellsize; return false; }
 };
 
 // Host memory for point buffers: page-locked and pooled when a GPU is there (the DMA engines then
@@ -239,7 +242,17 @@ public:
     // construction helpers
     int from_points(const cwipc_point *points, size_t size, int npoint, uint64_t timestamp, bool exact_size = true);
     void adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t timestamp, float cellsize, bool exact_size = false);
-    void adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize);
+    void adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize, bool late_metadata = false);
+    // What a library thread needs of this cloud to work on it after the caller has gone on (or freed the cloud): the planes, or
+    // the pending result that will become them.  A cloud that lives in host memory only is uploaded first (by the caller).
+    struct Snapshot {
+        std::shared_ptr<DeferredResult> pending;
+        std::shared_ptr<DeviceSoA> dev;
+        uint64_t timestamp = 0;
+        float cellsize = 0;
+        bool has_data = false;
+    };
+    Snapshot snapshot();
 
     // residency
     std::shared_ptr<DeviceSoA> device_points();   // uploads if needed; nullptr on failure
@@ -260,6 +273,7 @@ private:
     size_t m_npoints = 0;
     bool m_has_data = false;      // counts towards cwipc_dangling_allocations
     bool m_exact_size = false;    // from_points flavour: copy_uncompressed wants size == exact
+    bool m_late_metadata = false; // timestamp and cellsize come with the pending result
     std::shared_ptr<HostAoS> m_host;
     std::shared_ptr<DeviceSoA> m_dev;
     cwipc_metadata *m_metadata = nullptr;

@@ -2156,10 +2156,15 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.cus = cus_now;
         ws.cus_device = current_device();
     }
-    // CWIPC_SPARE_CUS=n leaves n compute units out of the persistent grid: a process that runs something else next
-    // to its downsamples (the multi-GPU join: pack, collective, unpack, all small) sets it, because K1's workgroups
-    // fill every CU they sit on and a kernel of another stream would otherwise wait for a whole K1 to finish.
-    static const int spare_cus = []() { const char *e = getenv("CWIPC_SPARE_CUS"); return e ? atoi(e) : 0; }();
+    // The persistent grid leaves one compute unit per XCD free (8 of 256 on MI355X).  In a stream of calls consecutive
+    // accumulate kernels run on the thread's two streams: the next one's workgroups start on the free CUs and take over the
+    // others as the previous kernel's workgroups finish, so one kernel's start-up and flush (about 10 of its 58 us, during
+    // which a CU streams nothing) lie behind the other's stream: 61.3 -> 52.5 us per call at 10 M points.  It takes a free CU
+    // on EVERY XCD (workgroups are dealt to the XCDs in turn: with 6 spare CUs nothing is gained, with 8 everything); a
+    // single kernel is as fast on 248 CUs as on 256 (58.8 / 58.5 us).  CWIPC_SPARE_CUS=n overrides (a process that runs a
+    // multi-GPU join next to its downsamples leaves a few more: the exchange's kernels need room too).
+    static const int spare_knob = []() { const char *e = getenv("CWIPC_SPARE_CUS"); return e ? atoi(e) : -1; }();
+    const int spare_cus = spare_knob >= 0 ? spare_knob : ws.cus / 32;
     const int cus = ws.cus - spare_cus > 8 ? ws.cus - spare_cus : ws.cus;
     // one persistent workgroup per CU; short clouds get fewer so that every wave has at least one step,
     // very large clouds get more (sequential) workgroups: the packed table needs < 65536 points per workgroup

@@ -136,15 +136,24 @@ cwipc_pointcloud *cwipc_hip_pointcloud::_shallowcopy() {
     return rv;
 }
 
-uint64_t cwipc_hip_pointcloud::timestamp() { return m_timestamp; }
-float cwipc_hip_pointcloud::cellsize() { return m_cellsize; }
-void cwipc_hip_pointcloud::_set_timestamp(uint64_t timestamp) { m_timestamp = timestamp; }
+uint64_t cwipc_hip_pointcloud::timestamp() {
+    if (m_late_metadata) settle();
+    return m_timestamp;
+}
+float cwipc_hip_pointcloud::cellsize() {
+    if (m_late_metadata) settle();
+    return m_cellsize;
+}
+void cwipc_hip_pointcloud::_set_timestamp(uint64_t timestamp) {
+    if (m_late_metadata) settle();   // (what is being set must not be overwritten when the pending result arrives)
+    m_timestamp = timestamp;
+}
 
 // reference :173-204 -- a negative value asks for the heuristic: minimum fp32
 // distance between every point and the FIRST point (prevPoint never advances).
 // Rare and O(N): done on the host copy.
 void cwipc_hip_pointcloud::_set_cellsize(float cellsize) {
-    if (cellsize < 0) settle();
+    if (cellsize < 0 || m_late_metadata) settle();
     if (cellsize < 0 && m_has_data) {
         auto host = host_points();
         float minDistance = std::numeric_limits<float>::infinity();
@@ -308,10 +317,11 @@ void cwipc_hip_pointcloud::adopt_device(std::shared_ptr<DeviceSoA> dev, uint64_t
     }
 }
 
-void cwipc_hip_pointcloud::adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize) {
+void cwipc_hip_pointcloud::adopt_deferred(std::shared_ptr<DeferredResult> pending, uint64_t timestamp, float cellsize, bool late_metadata) {
     std::lock_guard<std::mutex> lock(m_lock);
     m_timestamp = timestamp;
     m_cellsize = cellsize;
+    m_late_metadata = late_metadata;
     m_npoints = 0;
     m_dev.reset();
     m_host.reset();
@@ -331,9 +341,14 @@ void cwipc_hip_pointcloud::settle() {
     }
     if (!p) return;
     std::shared_ptr<DeviceSoA> r = p->settle();   // (idempotent: two threads settling at once get the same planes)
+    uint64_t late_ts = 0;
+    float late_cs = 0;
+    const bool late = p->late_metadata(&late_ts, &late_cs);
     std::lock_guard<std::mutex> lock(m_lock);
     if (m_pending != p) return;
     m_pending.reset();
+    if (late && m_late_metadata) { m_timestamp = late_ts; m_cellsize = late_cs; }
+    m_late_metadata = false;
     if (r) {
         m_dev = r;
         m_npoints = r->npoints;
@@ -342,6 +357,29 @@ void cwipc_hip_pointcloud::settle() {
         m_host = std::make_shared<HostAoS>();
         m_npoints = 0;
     }
+}
+
+cwipc_hip_pointcloud::Snapshot cwipc_hip_pointcloud::snapshot() {
+    Snapshot snap;
+    {
+        std::lock_guard<std::mutex> lock(m_lock);
+        snap.pending = m_pending;
+        if (!snap.pending) snap.dev = m_dev;
+        snap.has_data = m_has_data;
+    }
+    if (!snap.pending && !snap.dev && snap.has_data) snap.dev = device_points();   // host copy only: upload now
+    if (!snap.pending || !m_late_metadata) {
+        snap.timestamp = timestamp();
+        snap.cellsize = cellsize();
+    } else {
+        // a pending join as the input of another: its metadata come with it (settles here, rare)
+        snap.timestamp = timestamp();
+        snap.cellsize = cellsize();
+        std::lock_guard<std::mutex> lock(m_lock);
+        snap.pending.reset();
+        snap.dev = m_dev;
+    }
+    return snap;
 }
 
 // H2D: pinned staging -> device AoS -> de-interleave kernel -> SoA planes.

@@ -221,6 +221,7 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_comm_rank': ([_c.c_void_p], _c.c_int),
     'cwipc_hip_comm_nranks': ([_c.c_void_p], _c.c_int),
     'cwipc_hip_comm_join': ([_c.c_void_p, cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
+    'cwipc_hip_comm_submit': ([_c.c_void_p, cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_profile_enable': ([_c.c_int], None),
     'cwipc_hip_profile_reset': ([], None),
     'cwipc_hip_profile_count': ([], _c.c_int),
@@ -877,6 +878,14 @@ class cwipc_hip_comm:
             raise CwipcError("cwipc_hip_comm: used after free()")
         rv = self._dll.cwipc_hip_comm_join(self._comm, pc.as_cwipc_p() if pc is not None else None, CWIPC_HIP_JOIN_LOOPBACK if loopback else 0)
         return _wrap_filter_result('cwipc_hip_comm_join', rv)
+
+    def submit(self, pc: Optional[cwipc_pointcloud_wrapper], loopback: bool = False) -> cwipc_pointcloud_wrapper:
+        """join() for a stream of frames: returns at once; the fused cloud settles when it is first used (the exchange runs
+        on a thread of the communicator, in the order of the calls).  pc may be freed right away."""
+        if not self._comm:
+            raise CwipcError("cwipc_hip_comm: used after free()")
+        rv = self._dll.cwipc_hip_comm_submit(self._comm, pc.as_cwipc_p() if pc is not None else None, CWIPC_HIP_JOIN_LOOPBACK if loopback else 0)
+        return _wrap_filter_result('cwipc_hip_comm_submit', rv)
 
     def free(self) -> None:
         if self._comm:

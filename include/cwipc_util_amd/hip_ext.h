@@ -71,6 +71,13 @@ _CWIPC_UTIL_EXPORT int cwipc_hip_comm_nranks(cwipc_hip_comm *comm);
  * call returns when the group is enqueued (the result carries an event).  NULL on error (logged). */
 #define CWIPC_HIP_JOIN_LOOPBACK 1   /* this rank's own part travels through RCCL too (send/recv to itself): exercises the exchange on one GPU */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *comm, cwipc_pointcloud *pc, int flags);
+/* The same for a stream of frames: returns at once with a cloud that stands for the fused cloud of this frame; the exchange
+ * itself (waiting for this rank's filter results, the record all-gather, the send/recv group) is done by a thread of the
+ * communicator, frame after frame in the order of the calls, and the cloud settles when it is first used (count, a filter, a
+ * copy; its timestamp and cellsize too: they are the minimum over the ranks).  Every rank submits every frame, in the same
+ * order.  The argument may be freed as soon as the call returns.  A failed exchange shows as an empty cloud plus the logged
+ * error.  cwipc_hip_comm_free waits for the frames still queued. */
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_submit(cwipc_hip_comm *comm, cwipc_pointcloud *pc, int flags);
 
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */

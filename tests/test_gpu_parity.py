@@ -1450,6 +1450,49 @@ def test_library_exchange_on_one_rank(gpu, oracle, synth):
         comm.join(None)
 
 
+def test_library_exchange_stream_of_submitted_frames(gpu, oracle, synth):
+    """cwipc_hip_comm_submit: the fused cloud is handed out at once and the exchange happens on a thread of the communicator,
+    frame after frame in the order of the calls.  Inputs are freed right after the call (or are results of filters that are
+    still running), some frames have no tile, a plain join() in between takes its place in the queue; every result -- points,
+    count, and the timestamp and cellsize that only the exchange knows -- must be what join() gives."""
+    import gc
+    pts, cs = synth(100000)
+    comm = gpu.cwipc_hip_comm(gpu.cwipc_hip_comm_unique_id(), 0, 1)
+    try:
+        for loopback in (False, True):
+            frames = [pts[:3000], pts[:3501], pts[:0], None, pts[5000:5000 + 40000], pts[:1], None, pts[:90000], pts[200:703]]
+            handed = []
+            for i, f in enumerate(frames):
+                pc = None
+                if f is not None:
+                    pc = make_cloud(gpu, f, cs + i, 1000 + i)
+                    gpu.cwipc_hip_upload(pc, drop_host_copy=(i % 2 == 0))
+                handed.append(comm.submit(pc, loopback=loopback))
+                if pc is not None:
+                    pc.free(force=True)
+                    del pc
+                if i == 4:   # a waiting call between submitted ones: exchanged in its turn
+                    mid = comm.join(make_cloud(gpu, pts[:777], 3.0, 42), loopback=loopback)
+                    assert same(mid.get_numpy_array(), pts[:777]) and mid.timestamp() == 42 and mid.cellsize() == 3.0
+            gc.collect()
+            for i, (f, out) in enumerate(zip(frames, handed)):
+                if f is None:
+                    assert out.count() == 0 and out.timestamp() == 0 and out.cellsize() == 0.0, (loopback, i)
+                else:
+                    assert out.timestamp() == 1000 + i and out.cellsize() == np.float32(cs + i), (loopback, i)   # (before the points are asked for)
+                    assert same(out.get_numpy_array(), f), (loopback, i)
+        # results of filters that are still running when they are submitted; the fused cloud goes straight into another filter
+        pc = make_cloud(gpu, pts, cs, 5)
+        want = gpu.cwipc_downsample(pc, 0.02).get_numpy_array()
+        outs = [comm.submit(gpu.cwipc_downsample(pc, 0.02), loopback=True) for _ in range(6)]
+        for out in outs:
+            assert out.cellsize() == np.float32(0.02) and same(out.get_numpy_array(), want)
+        again = gpu.cwipc_tilefilter(comm.submit(gpu.cwipc_downsample(pc, 0.02)), 1)
+        assert same(again.get_numpy_array(), want[want['tile'] == 1])
+    finally:
+        comm.free()
+
+
 def test_library_exchange_refuses_what_cannot_work(gpu, monkeypatch):
     """Between processes RCCL needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver: without it the communicator is refused at
     creation (before any rank can be left waiting inside a collective); bad ranks and ids are refused too."""
