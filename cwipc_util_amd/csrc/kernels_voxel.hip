@@ -2483,7 +2483,18 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
 
         uint32_t err = hw[C_ERR];
 #ifdef CWIPC_DEBUG_KNOBS
-        if (used_fast) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "debug: slab refits in this pass: " + std::to_string(hw[30]) + " (waves: " + std::to_string(nwaves) + ")");
+        if (used_fast && getenv("CWIPC_FAST_STAMPS")) {
+            unsigned long long st[2][16];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fast_stamps), sizeof(st)) == hipSuccess) {
+                for (int w = 0; w < 2; w++) {
+                    std::string line = "debug: workgroup " + std::string(w ? "mid" : "0") + " phases (us since its start): ";
+                    const char *names[9] = {"start", "table ready", "steps done", "boxes out", "entries compacted", "keys decoded", "leaf ids", "records updated", "end"};
+                    for (int i = 1; i < 9; i++) line += std::string(names[i]) + " " + std::to_string((double)(st[w][i] - st[w][0]) * 0.01).substr(0, 5) + "; ";
+                    cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", line);
+                }
+            }
+        }
 #endif
         {
             // adapt the workgroup size for the next call
