@@ -2363,7 +2363,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         if (fast) {
             FastParams F;
             memset(&F, 0, sizeof(F));
-            F.n = K.n; F.per_wave = K.per_wave; F.inv_leaf = K.inv_leaf;
+            F.n = K.n; F.per_wg = K.per_wave * K1_WAVES; F.inv_leaf = K.inv_leaf;
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
@@ -2386,7 +2386,13 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         } else {
             CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);
         }
-        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, P, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
+        // (the fast variant leaves one box per workgroup range, the general one and the partition pass one per wave range)
+        VoxParams Pr = P;
+        if (fast) {
+            Pr.per_wave = P.per_wave * K1_WAVES;
+            Pr.nranges = nblocks;
+        }
+        CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, Pr, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
                   ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), ws.host_words, seq);
         const hipError_t launch_err = hipGetLastError();
         ok = launch_err == hipSuccess;
@@ -2491,6 +2497,12 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                     std::string line = "debug: workgroup " + std::string(w ? "mid" : "0") + " phases (us since its start): ";
                     const char *names[9] = {"start", "table ready", "steps done", "boxes out", "entries compacted", "keys decoded", "leaf ids", "records updated", "end"};
                     for (int i = 1; i < 9; i++) line += std::string(names[i]) + " " + std::to_string((double)(st[w][i] - st[w][0]) * 0.01).substr(0, 5) + "; ";
+                    cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", line);
+                }
+                unsigned long long wd[K1_WAVES];
+                if (hipMemcpyFromSymbol(wd, HIP_SYMBOL(g_fast_wave_done), sizeof(wd)) == hipSuccess) {
+                    std::string line = "debug: workgroup 0, waves done with their steps at (us):";
+                    for (int w = 0; w < K1_WAVES; w++) line += " " + std::to_string((double)(wd[w] - st[0][0]) * 0.01).substr(0, 5);
                     cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", line);
                 }
             }
