@@ -10,9 +10,14 @@
 //
 // The k nearest distances of a point are a well-defined multiset, so d_i does not
 // depend on how the neighbour search is organised.  Here: points are bucketed
-// into a uniform grid (counting sort), each lane searches growing cubic shells
-// of cells around its point and keeps the k+1 smallest distances in LDS; a shell
+// into a uniform grid by a counting sort (one atomic per run of equal cells in a wave), each lane
+// searches growing cubic shells of cells around its point -- its own row of cells first, rows that can
+// no longer hold one of the k + 1 nearest skipped -- and keeps the k + 1 smallest distances as a sorted list
+// in registers (insert = one v_med3 per slot; k <= 32; an LDS list up to k = 120); a shell
 // radius r proves exactness once the (k+1)-th distance is <= r*h.
+// Two layouts of the grid: dense (small and medium clouds; the grid itself -- box, cell size from an
+// occupancy census -- is decided by two one-wave kernels on the device, no host round trip), and sparse
+// (from 2^20 points: segments of 16 cells along x that exist only where points are, see SEG below).
 #include "internal.hpp"
 #include <vector>
 
