@@ -2360,10 +2360,17 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             Wk.bboxes = ws.bboxes + (size_t)ws.bbox_cap * 6;   // the boxes of the moved points: nobody reads them
         }
         used_fast = fast;
+        uint32_t fast_blocks = 0, fast_per_wg = 0;
         if (fast) {
             FastParams F;
             memset(&F, 0, sizeof(F));
-            F.n = K.n; F.per_wg = K.per_wave * K1_WAVES; F.inv_leaf = K.inv_leaf;
+            // The workgroups' ranges: the cloud's steps dealt evenly over the CUs the grid may use (a workgroup's waves share its
+            // range step by step, so a range need not be a multiple of sixteen steps): a 300 k-point cloud gets 235 workgroups
+            // of 5 steps, five busy waves each, instead of 74 workgroups whose sixteen waves queue up on four SIMDs.
+            const size_t wg_steps = std::min<size_t>(std::max<size_t>((steps_total + (size_t)cus - 1) / (size_t)cus, 1), MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP);
+            fast_blocks = (uint32_t)((steps_total + wg_steps - 1) / wg_steps);
+            fast_per_wg = (uint32_t)(wg_steps * WAVE_STEP);
+            F.n = K.n; F.per_wg = fast_per_wg; F.inv_leaf = K.inv_leaf;
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
@@ -2373,10 +2380,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             F.dbg = fast_dbg;
 #endif
             if (mode == 0) {
-                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<0>, dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
             } else {
-                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<1>, dim3(nblocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<1>, dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
             }
         } else if (mode == 0) {
@@ -2389,8 +2396,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         // (the fast variant leaves one box per workgroup range, the general one and the partition pass one per wave range)
         VoxParams Pr = P;
         if (fast) {
-            Pr.per_wave = P.per_wave * K1_WAVES;
-            Pr.nranges = nblocks;
+            Pr.per_wave = fast_per_wg;
+            Pr.nranges = fast_blocks;
         }
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, Pr, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
                   ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), ws.host_words, seq);
