@@ -144,13 +144,13 @@ struct VoxParams {
     int ib[3];              // cell c of leaf l on axis a is voxel  c + ib[a] + 64*l - 2
     int face_base[3];       // faces[a][i] is the threshold of face face_base[a] + i
     int leaf_split;
-    uint32_t leaf_mask;     // leaf hash capacity - 1
+    uint32_t leaf_mask;     // capacity of the leaf hash - 1 (the hash has four slots per leaf grid)
     uint32_t list_cap;
     uint32_t ablate;        // diagnostics only (CWIPC_VOXEL_ABLATE): skip parts of K1 to time the rest; results are wrong when non-zero
 };
 
 struct VoxWork {
-    unsigned long long *leaf_keys;   // [leaf hash] 0 = empty, else packed lattice coordinates | 1<<63 ; position = leaf id
+    unsigned long long *leaf_keys;   // [leaf id] 0 = none yet, else packed lattice coordinates | 1<<63 (ids are handed out in order of arrival)
     unsigned long long *records;     // [leaf hash][CELLS][8]
     uint32_t *occupied;              // list of (leaf id << 19 | cell) of touched records
     uint32_t *ctrl;
@@ -158,6 +158,8 @@ struct VoxWork {
     const float *faces;              // [3][FACES] thresholds (positive cellsize only)
     uint32_t *bitmaps;               // [leaf hash][BITWORDS] occupancy of the leaf grids (bit = cell)
     uint32_t *seg_count;             // [leaf hash][RANK_SEGS] occupied cells per bitmap slice (accumulated by K1's flush)
+    unsigned long long *hash_keys;   // [4 x leaf grids] leaf -> id: open addressing on the packed coordinates ...
+    uint32_t *hash_ids;              //   ... and the id + 1 of the entry's leaf (0: not published yet, ~0: no grid left)
 };
 
 inline __host__ __device__ uint64_t mix64(uint64_t k) {
@@ -262,17 +264,39 @@ float voxel_upper_bound(float inv_leaf, int voxel) {
 // global side: leaf lookup, record updates
 // ---------------------------------------------------------------------------
 // One lane: returns the id (hash position) of leaf key k, inserting it if new.
+// The id (= grid) of leaf k, giving it the next free one if the pass has not met it yet; ~0 when the grids have run out
+// (ERR_LEAVES is set: the host regrows and reruns).  The hash has four slots per grid: with one slot per grid (round 1: the
+// slot WAS the id) a person-sized cloud's 12-16 leaves filled a 16-slot table and every lookup walked it, one global round
+// trip per probe -- 5-10 us in the flush of every workgroup (time stamps of the debug-knob build).  Whoever claims a slot
+// publishes the id right behind the claim; a lane that finds the key but not yet the id looks again in the SAME loop (no
+// inner wait: lanes of one wave may be on either side).
 __device__ __forceinline__ uint32_t leaf_lookup(const VoxWork &W, uint32_t mask, unsigned long long k) {
+    const uint32_t cap = (mask + 1u) >> 2;
     uint32_t pos = (uint32_t)mix64(k) & mask;
-    for (uint32_t probe = 0; probe <= mask; probe++) {
-        unsigned long long cur = __hip_atomic_load(&W.leaf_keys[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == k) return pos;
+    uint32_t probes = 0;
+    for (uint32_t guard = 0; guard < (1u << 22); guard++) {
+        unsigned long long cur = __hip_atomic_load(&W.hash_keys[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0ull) {
-            unsigned long long old = atomicCAS(&W.leaf_keys[pos], 0ull, k);
-            if (old == 0ull) atomicAdd(&W.ctrl[C_LEAVES], 1u);
-            if (old == 0ull || old == k) return pos;
+            cur = atomicCAS(&W.hash_keys[pos], 0ull, k);
+            if (cur == 0ull) {
+                const uint32_t id = atomicAdd(&W.ctrl[C_LEAVES], 1u);
+                if (id < cap) {
+                    W.leaf_keys[id] = k;
+                    __hip_atomic_store(&W.hash_ids[pos], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return id;
+                }
+                atomicOr(&W.ctrl[C_ERR], ERR_LEAVES);
+                __hip_atomic_store(&W.hash_ids[pos], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0xffffffffu;
+            }
+        }
+        if (cur == k) {
+            const uint32_t v = __hip_atomic_load(&W.hash_ids[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0u) return v == 0xffffffffu ? 0xffffffffu : v - 1u;
+            continue;   // claimed a moment ago, id on its way
         }
         pos = (pos + 1) & mask;
+        if (++probes > mask) break;
     }
     atomicOr(&W.ctrl[C_ERR], ERR_LEAVES);
     return 0xffffffffu;
@@ -1855,6 +1879,8 @@ struct Workspace {
     float hint_cell = 0.f;
     bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
     unsigned long long *leaf_keys = nullptr;
+    unsigned long long *hash_keys = nullptr;
+    uint32_t *hash_ids = nullptr;
     unsigned long long *records = nullptr;
     uint32_t *occupied = nullptr;
     uint32_t *order = nullptr;         // records in output order (finalize pass), list_cap entries
@@ -1974,7 +2000,7 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         if (ws.bitmaps) (void)hipFree(ws.bitmaps);
         ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr;
         ws.records = nullptr; ws.bitmaps = nullptr; ws.leaf_cap = 0;
-        ws.head_bytes = HEAD_CTRL_BYTES + (size_t)leaf_cap * 8 + (size_t)leaf_cap * RANK_SEGS * sizeof(uint32_t);
+        ws.head_bytes = HEAD_CTRL_BYTES + (size_t)leaf_cap * 8 + (size_t)leaf_cap * RANK_SEGS * sizeof(uint32_t) + (size_t)leaf_cap * 4 * (8 + 4);
         ws.head_bytes = (ws.head_bytes + 255) & ~(size_t)255;
         CW_HIP_TRY(hipMalloc(&ws.head, 2 * ws.head_bytes));
         ws.head_clean[0] = ws.head_clean[1] = false;
@@ -2138,7 +2164,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             ws.last_m = 0;
             ws.streak = 0;
             if (p->err & (ERR_FAST_PATH | ERR_CELL_RANGE)) ws.no_fast = true;
-            VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count};
+            VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
             CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
             if (!c.sync()) { hip_failed(hipGetLastError(), "voxel workspace clean-up", __FILE__, __LINE__); return nullptr; }
         }
@@ -2296,7 +2322,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     bool used_fast = false;
     for (int attempt = 0; attempt < 10; attempt++) {
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
-        P.leaf_mask = ws.leaf_cap - 1;
+        P.leaf_mask = 4 * ws.leaf_cap - 1;
         P.list_cap = (uint32_t)(ws.list_cap > 0xffffffffu ? 0xffffffffu : ws.list_cap);
         const uint32_t seq = ++ws.seq ? ws.seq : ++ws.seq;
         for (int i = 0; i < C_SEQ; i++) ws.host_words[2 * i + 1] = 0;   // the tags of the words the replay kernel will publish
@@ -2306,7 +2332,9 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.ctrl = (uint32_t *)head;
         ws.leaf_keys = (unsigned long long *)(head + HEAD_CTRL_BYTES);
         ws.seg_count = (uint32_t *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8);
-        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count};
+        ws.hash_keys = (unsigned long long *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8 + (size_t)ws.leaf_cap * RANK_SEGS * sizeof(uint32_t));
+        ws.hash_ids = (uint32_t *)((char *)ws.hash_keys + (size_t)ws.leaf_cap * 4 * 8);
+        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
         bool ok = true;
         if (!ws.head_clean[blk]) ok = hipMemsetAsync(head, 0, ws.head_bytes, c.stream) == hipSuccess;
         ws.head_clean[blk] = false;

@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import cwipc_util_amd as cw
 from bench import make_input
-for npts in (300000, 2000000, 10000000):
+for npts in (300000, 10000000):
     pc = make_input(cw, npts, 0.0)
     cw.cwipc_hip_upload(pc, drop_host_copy=True)
     for _ in range(6): cw.cwipc_downsample(pc, 0.01).count()
