@@ -12,16 +12,19 @@ result out while its kernels still run (it settles on first use); the timed regi
 
 N > 1 (weak scaling): every rank holds one camera tile of the same size (tile mask 1 << rank),
 runs the same step on its own GPU, and the per-rank results are fused by the all-gatherv join -- the path's one
-exchange step: RCCL inside the library (cwipc_hip_comm_join, one C call per frame; CWIPC_BENCH_EXCHANGE=torch selects
-the same protocol on torch.distributed, cwipc_util_amd.multigpu, which is also what the bench falls back to, on all
-ranks together, should the library's exchange fail its preflight against it -- a comparison on a real frame, under a
-time limit).  Frames stream: the join of frame i runs on a worker thread while the main thread downsamples frame
-i + 1 (at most two frames in flight; all joins are complete when the timed region ends).  For N > 1 the library is
-told to leave 24 compute units out of the voxel kernel's persistent grid (CWIPC_SPARE_CUS, unless already set), so that
-the join's kernels do not wait for a whole downsample.  Rehearsal knobs: CWIPC_BENCH_BACKEND=gloo (several ranks on one
-GPU, exchange staged through the host), CWIPC_BENCH_FORCE_JOIN=1 (N = 1 with a one-rank RCCL group: the whole N > 1
-step but the wire), CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other), CWIPC_BENCH_JOIN_ASYNC=0 (torch
-exchange: the worker waits for every frame's collective before it takes the next frame).
+exchange step: RCCL inside the library, pipelined inside the library (cwipc_hip_comm_submit: one C call per frame that
+returns at once; a thread of the communicator does the waiting, so the join of frame i overlaps the downsample of frame
+i + 1; all joins are complete when the timed region ends).  torch.distributed runs on gloo and only carries the
+communicator's id, the fences and the sum of the timing: a torch NCCL process group in the process costs every step ~20 us
+whether it is used or not.  CWIPC_BENCH_EXCHANGE=torch selects the same protocol on torch.distributed
+(cwipc_util_amd.multigpu, with a Python worker thread and an RCCL process group made for it), which is also what the
+bench falls back to, on all ranks together, should the library's exchange fail its preflight against it -- a comparison
+on a real frame, under a time limit.  For N > 1 the library is told to leave 24 compute units out of the voxel kernel's
+persistent grid (CWIPC_SPARE_CUS, unless already set; the default is one per XCD), so that the exchange's kernels find
+room.  Rehearsal knobs: more ranks than GPUs (several ranks share a GPU, torch exchange staged through the host),
+CWIPC_BENCH_FORCE_JOIN=1 (N = 1 with a one-rank communicator: the whole N > 1 step but the wire),
+CWIPC_BENCH_PIPELINE=0 (join and downsample one after the other), CWIPC_BENCH_JOIN_ASYNC=0 (torch exchange: the worker
+waits for every frame's collective before it takes the next frame).
 
 One JSON line on rank 0, the only thing written to stdout.  `value` = points filtered by all ranks / wall time of the K
 timed steps (max over ranks), inputs resident in HBM.  `roofline` = algorithmic bytes of the dominant kernel (16 B per
