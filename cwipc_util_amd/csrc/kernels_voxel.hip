@@ -2379,7 +2379,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                 hip_failed(hipGetLastError(), "voxel partition setup", __FILE__, __LINE__);
                 return nullptr;
             }
-            CW_LAUNCH("partition_count", partition_count_kernel, dim3(nblocks), dim3(K1_THREADS), 0, c.stream, (uint32_t)n, (uint32_t)P.per_wave, P.inv_leaf,
+            CW_LAUNCH("partition_count", partition_count_kernel, dim3(nblocks), dim3(K1_THREADS), 0, c.stream, (uint32_t)n, (uint32_t)(P.per_wave * K1_WAVES), P.inv_leaf,
                       src.x(), src.y(), src.z(), ws.bboxes, ws.part_hist, ws.ctrl);
             CW_LAUNCH("partition_scan", partition_scan_kernel, dim3(1), dim3(K1_THREADS), 0, c.stream, ws.part_hist);
             CW_LAUNCH("partition_scatter", partition_scatter_kernel, dim3((unsigned)((n + PART_CHUNK - 1) / PART_CHUNK)), dim3(K1_THREADS), sizeof(PartLds), c.stream,
@@ -2421,11 +2421,14 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         } else {
             CW_LAUNCH("voxel_accumulate_exact", voxel_accumulate_kernel<2>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);
         }
-        // (the fast variant leaves one box per workgroup range, the general one and the partition pass one per wave range)
+        // (the fast variant and the partition pass leave one box per workgroup range, the general variant one per wave range)
         VoxParams Pr = P;
         if (fast) {
             Pr.per_wave = fast_per_wg;
             Pr.nranges = fast_blocks;
+        } else if (partition) {   // the counting kernel's boxes: one per workgroup range of the cloud as it came
+            Pr.per_wave = P.per_wave * K1_WAVES;
+            Pr.nranges = nblocks;
         }
         CW_LAUNCH("octree_replay", octree_replay_kernel, dim3(1), dim3(1024), 0, c.stream, Pr, src.x(), src.y(), src.z(), ws.bboxes, ws.ctrl,
                   ws.leaf_keys, ws.leaf_cap, (uint32_t *)next_head, (uint32_t)(ws.head_bytes / 4), ws.host_words, seq);
