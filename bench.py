@@ -247,6 +247,12 @@ def main() -> None:
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if world > 1:
+        # RCCL hands device buffers from process to process with HIP IPC, and this image's host driver supports only the dmabuf
+        # flavour: without this setting the library refuses to make a communicator between processes (and torch's RCCL group
+        # would die in hipIpcGetMemHandle).  Set here, before torch or the library is imported -- nothing has touched the
+        # GPU yet, so the process needs no restart.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 or os.environ.get("CWIPC_BENCH_FORCE_JOIN") == "1":
         # the join's small kernels (pack, collective, unpack) run next to the next frame's downsample: leave them a few
         # compute units (the library reads this when it is first used)
@@ -522,7 +528,7 @@ def main() -> None:
                 "input_copies_rotated": NCOPIES,
                 "inputs_resident_in_hbm": True,
                 **({"voxel_kernel_spare_cus": int(os.environ.get("CWIPC_SPARE_CUS", "0")), "exchange": exchange} if joining else {}),
-                **({"exchange_note": exchange_note} if exchange_note else {}),
+                **({"exchange_fallback": True, "exchange_note": exchange_note} if exchange_note else {}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -557,8 +563,11 @@ def main() -> None:
         os.dup2(2, 1)
 
     if joining and abandon_at_exit:
+        # a thread of some rank is still inside a collective that never completed: a GPU-side hang.  The line is out (with
+        # `exchange_fallback`); the status says that this run is NOT a clean record of the library's exchange.
+        print(f"[rank {rank}] ending with status 3: the preflight of the library's exchange hung on some rank", file=sys.stderr)
         sys.stderr.flush()
-        os._exit(0)   # a thread of this process is still inside a collective that never completed
+        os._exit(3)
     if joiner is not None:
         joiner.todo.put(None)
         joiner.thread.join()

@@ -5,20 +5,27 @@
 // Here every rank has filtered its own tile on its own GPU; the fused cloud (rank order = tile order = the reference's
 // fold order; timestamp and cellsize = the minimum over the contributing clouds, src/cwipc_filters.cpp:411-414) is put
 // together on every rank by
-//   1. one ncclAllGather of a 32-byte record per rank (count, has-cloud flag, cellsize bits, timestamp), read back by the host:
-//      the one wait of the call -- the counts size the result and the receives;
-//   2. one group of ncclSend / ncclRecv: this rank's four planes to every other rank, every other rank's planes from it,
-//      received straight into the result's planes at the prefix-sum displacement.  The clouds are SoA on both sides, so
-//      there is no pack or unpack kernel and no padding on the wire; the rank's own part is one copy kernel.
+//   1. one ncclAllGather of a 32-byte record per rank (count, has-cloud flag, cellsize bits, timestamp, what the rank can do
+//      this frame, and how much room for the fused cloud it already holds), read back by the host: the one wait of the call --
+//      the counts size the result and the receives.  Only when some rank has to allocate its result now (the first frame, a
+//      frame that outgrew the last one by more than 25 %) the ranks meet once more, 4 bytes each, so that a rank that could
+//      not is known to all BEFORE payload moves;
+//   2. one group of ncclSend / ncclRecv as exchange_plan.hpp lays it out from the gathered records alone: this rank's four
+//      planes to every other rank that builds a fused cloud, every other rank's planes from it, received straight into the
+//      result's planes at the prefix-sum displacement.  The clouds are SoA on both sides, so there is no pack or unpack
+//      kernel and no padding on the wire; the rank's own part is one copy kernel.  A rank whose tile is the whole frame hands
+//      its input on as the result -- and still sends it to the others.
 // The call returns when the group has been enqueued: the result carries a `ready` event like every asynchronous filter
 // result, the input is kept until the sends have read it.
 //
 // cwipc_util_amd/multigpu.py holds the same protocol on torch.distributed (all_gather of padded slots); it runs on gloo
 // without a GPU, which is how the world-size-2 and -3 tests cover the host logic.  The two are compared on the device.
 #include "internal.hpp"
+#include "exchange_plan.hpp"
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -28,15 +35,7 @@ namespace cwipc_amd {
 
 namespace {
 
-struct FrameMeta {          // what every rank tells the others about its part of the frame: 8 words
-    uint32_t count;
-    uint32_t has_cloud;
-    uint32_t cellsize_bits;
-    uint32_t pad0;
-    uint32_t ts_lo, ts_hi;
-    uint32_t pad1, pad2;
-};
-static_assert(sizeof(FrameMeta) == 32, "FrameMeta travels as 8 uint32");
+using xplan::FrameMeta;
 
 bool nccl_failed(ncclResult_t r, const char *what, char **errorMessage) {
     std::string msg = std::string(what) + ": " + ncclGetErrorString(r);
@@ -92,10 +91,11 @@ struct cwipc_hip_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
     hipStream_t stream = nullptr;
-    FrameMeta *meta_host = nullptr;     // pinned: [0] = ours going out, [1 .. nranks] = everybody's coming back
+    FrameMeta *meta_host = nullptr;     // pinned: [0] = ours going out, [1 .. nranks] = everybody's coming back; then nranks + 1 status words likewise
     FrameMeta *meta_dev = nullptr;      // the same layout in device memory
     std::mutex lock;                    // one frame at a time per communicator (collectives must be issued in one order)
     unsigned long long frames = 0;
+    size_t expect_points = 0;           // room taken for the next frame's fused cloud before the ranks meet (last frame's size + 25 %)
     // cwipc_hip_comm_submit: frames wait here for the communicator's thread, which takes them in the order they came
     std::mutex queue_lock;
     std::condition_variable queue_cv;
@@ -143,8 +143,8 @@ extern "C" cwipc_hip_comm *cwipc_hip_comm_create(const void *id, int rank, int n
     ncclResult_t r = ncclCommInitRank(&cm->comm, nranks, uid, rank);
     if (r != ncclSuccess) { nccl_failed(r, "ncclCommInitRank", errorMessage); return nullptr; }
     bool ok = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipHostMalloc((void **)&cm->meta_host, sizeof(FrameMeta) * (nranks + 1), hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void **)&cm->meta_dev, sizeof(FrameMeta) * (nranks + 1)) == hipSuccess;
+              hipHostMalloc((void **)&cm->meta_host, sizeof(FrameMeta) * (nranks + 1) + 4 * (nranks + 1), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&cm->meta_dev, sizeof(FrameMeta) * (nranks + 1) + 4 * (nranks + 1)) == hipSuccess;
     if (!ok) {
         hip_failed(hipGetLastError(), "cwipc_hip_comm_create", __FILE__, __LINE__);
         cwipc_hip_comm_free(cm.release());
@@ -180,20 +180,68 @@ struct JoinOutcome {
     float cellsize = 0;
 };
 
+// The communicator's device for the duration of a call, whatever the calling thread had selected.
+struct DeviceGuard {
+    int before = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want) {
+        if (hipGetDevice(&before) == hipSuccess && before != want) switched = hipSetDevice(want) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(before); }
+};
+
+// One gather of `words` uint32 per rank through the communicator's stream, read back by the host (the wait of the call).
+// `mine_host` / `all_host` are pinned, `mine_dev` / `all_dev` device memory.
+bool gather_words(cwipc_hip_comm *cm, const void *mine_host, void *mine_dev, void *all_dev, void *all_host, size_t words, const char *who) {
+    const int W = cm->nranks;
+    bool ok = hipMemcpyAsync(mine_dev, mine_host, words * 4, hipMemcpyHostToDevice, cm->stream) == hipSuccess;
+    if (ok) {
+        ncclResult_t r = ncclAllGather(mine_dev, all_dev, words, ncclUint32, cm->comm, cm->stream);
+        if (r != ncclSuccess) { nccl_failed(r, "ncclAllGather", nullptr); return false; }
+    }
+    ok = ok && hipMemcpyAsync(all_host, all_dev, words * 4 * W, hipMemcpyDeviceToHost, cm->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(cm->stream) == hipSuccess;
+    if (!ok) hip_failed(hipGetLastError(), who, __FILE__, __LINE__);
+    return ok;
+}
+
 // One frame's exchange, once this rank's part is known: `src` are its planes (nullptr: no tile this frame, or a tile that
 // could not be read -- bad_input -- which the other ranks see as "no tile" while this rank's call fails).  The caller holds
 // cm->lock.
+//
+// Every exit before the payload group is COLLECTIVE: what only this rank knows (no usable device context, no memory for the
+// fused cloud) goes into its record and the plan (exchange_plan.hpp), a function of the gathered records alone, leaves the
+// rank out on every side.  A rank never leaves between the gather and the group on grounds the others cannot see.
 JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint64_t src_ts, float src_cs, bool bad_input, bool loopback) {
     const char *who = "cwipc_hip_comm_join";
     JoinOutcome none;
+    const int W = cm->nranks;
+    const bool wire = W > 1 || loopback;
     ThreadCtx &c = tctx();
-    if (!c.ensure()) return none;
-    if (current_device() != cm->device) {
-        cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "the communicator was made for another device");
-        return none;
+    uint32_t my_status = xplan::ST_OK;
+    if (!c.ensure()) {
+        my_status = xplan::ST_ABSENT;   // (logged by ensure)
+    } else if (current_device() != cm->device) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "the communicator was made for another device: this rank's tile is left out of the frame");
+        my_status = xplan::ST_ABSENT;
     }
+    if (my_status != xplan::ST_OK && !wire) return none;
+    DeviceGuard on_device(cm->device);
     if (src && src->npoints >= ((size_t)1 << 32)) { bad_input = true; src = nullptr; }
+    if (my_status != xplan::ST_OK) src = nullptr;
+
+    // room for the fused cloud, taken BEFORE the ranks meet: sized from the last frame, so that in a stream of frames nobody
+    // has to allocate between the gather and the payload (and nobody can fail there unseen)
+    std::shared_ptr<DeviceSoA> room;
+    size_t room_points = 0;
+    if (wire && my_status == xplan::ST_OK && cm->expect_points) {
+        room = soa_alloc(cm->expect_points);
+        if (room) room_points = cm->expect_points;
+    }
+
     FrameMeta mine{};
+    mine.status = my_status;
+    mine.capacity = (uint32_t)std::min<size_t>(room_points, 0xffffffffu);
     if (src) {
         const float cs = src_cs;
         const uint64_t ts = src_ts;
@@ -205,38 +253,38 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
     }
 
     // 1. everybody's record
-    const int W = cm->nranks;
     FrameMeta *all = cm->meta_host + 1;
-    if (W == 1 && !loopback) {
+    if (!wire) {
         all[0] = mine;
     } else {
         cm->meta_host[0] = mine;
-        bool ok = hipMemcpyAsync(cm->meta_dev, cm->meta_host, sizeof(FrameMeta), hipMemcpyHostToDevice, cm->stream) == hipSuccess;
-        ncclResult_t r = ok ? ncclAllGather(cm->meta_dev, cm->meta_dev + 1, sizeof(FrameMeta) / 4, ncclUint32, cm->comm, cm->stream) : ncclSuccess;
-        if (r != ncclSuccess) { nccl_failed(r, "ncclAllGather", nullptr); return none; }
-        ok = ok && hipMemcpyAsync(all, cm->meta_dev + 1, sizeof(FrameMeta) * W, hipMemcpyDeviceToHost, cm->stream) == hipSuccess;
-        ok = ok && hipStreamSynchronize(cm->stream) == hipSuccess;
-        if (!ok) { hip_failed(hipGetLastError(), who, __FILE__, __LINE__); return none; }
+        if (!gather_words(cm, cm->meta_host, cm->meta_dev, cm->meta_dev + 1, all, sizeof(FrameMeta) / 4, who)) return none;
     }
     cm->frames++;
 
-    // 2. what the fused cloud looks like
-    std::vector<size_t> disp(W + 1, 0);
-    bool any = false;
-    uint64_t ts_min = 0;
-    float cs_min = 0;
-    for (int r = 0; r < W; r++) {
-        disp[r + 1] = disp[r] + all[r].count;
-        if (!all[r].has_cloud) continue;
-        const uint64_t ts = ((uint64_t)all[r].ts_hi << 32) | all[r].ts_lo;
-        float cs;
-        memcpy(&cs, &all[r].cellsize_bits, 4);
-        if (!any || ts < ts_min) ts_min = ts;
-        if (!any || cs < cs_min) cs_min = cs;
-        any = true;
+    // 1b. only if some rank has to allocate now: one more meeting, so that a rank that cannot is known to all
+    if (wire && xplan::needs_second_round(W, all, loopback)) {
+        const size_t total = xplan::frame_total(W, all);
+        uint32_t word = my_status;
+        if (xplan::needs_buffer(cm->rank, W, all, loopback) && room_points < total) {
+            room = soa_alloc(total + total / 4 + 1024);
+            room_points = room ? total + total / 4 + 1024 : 0;
+            if (!room) {
+                cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "out of device memory for the fused cloud: this rank sends its tile and gets no result");
+                word = xplan::ST_NO_RECV;
+            }
+        }
+        uint32_t *status_host = reinterpret_cast<uint32_t *>(cm->meta_host + 1 + W);   // [0] ours, [1 .. W] everybody's
+        uint32_t *status_dev = reinterpret_cast<uint32_t *>(cm->meta_dev + 1 + W);
+        status_host[0] = word;
+        if (!gather_words(cm, status_host, status_dev, status_dev + 1, status_host + 1, 1, who)) return none;
+        for (int r = 0; r < W; r++)
+            if (all[r].status == xplan::ST_OK) all[r].status = status_host[1 + r];
     }
-    const size_t total = disp[W];
-    if (total >= ((size_t)1 << 32)) {
+
+    // 2. what this rank does (a function of the records alone: the ranks' plans fit together)
+    const xplan::FramePlan plan = xplan::plan_frame(cm->rank, W, all, loopback);
+    if (plan.too_big) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "the fused cloud would hold 2^32 points or more");
         return none;   // every rank sees the same counts and takes the same way out: nobody is left waiting
     }
@@ -245,53 +293,54 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
             cwipc_log(CWIPC_LOG_LEVEL_WARNING, who, "cannot read the point data of the argument (the other ranks got a frame without this tile)");
             return none;
         }
+        if (plan.no_result) return none;
         JoinOutcome out;
         out.planes = std::move(planes);
-        out.timestamp = ts_min;
-        out.cellsize = cs_min;
+        out.timestamp = plan.ts_min;
+        out.cellsize = plan.cs_min;
         return out;
     };
-    const size_t n_me = all[cm->rank].count;
-    // all points are this rank's own: the result holds its planes, nothing moves (cwipc_hip_join_multi's rule)
-    if (total > 0 && n_me == total && !loopback) return finish(src);
+    if (plan.total == 0) return finish(plan.no_result ? nullptr : soa_alloc(0));   // nothing moves for an empty frame
 
-    auto dst = soa_alloc(total);
-    if (!dst) {
-        // no result here, but the others will send: take what they send into nothing?  There is no such thing; a rank that
-        // cannot allocate its result cannot stay in step, and saying so loudly is all that is left.
-        cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "out of device memory for the fused cloud: this rank leaves the exchange");
-        return none;
+    std::shared_ptr<DeviceSoA> dst;
+    if (!plan.no_result && !plan.share_input) {
+        dst = room;     // big enough by construction: planned as a receiver only with capacity >= total or a fresh allocation
+        if (!dst || room_points < plan.total) {
+            // cannot happen while plan and records agree; if it does, the group below would write out of bounds: do not issue it
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "internal error: no room for the fused cloud after the ranks agreed there was");
+            return none;
+        }
+        dst->npoints = plan.total;   // (the planes keep their spacing, as after a compaction)
+        cm->expect_points = plan.total + plan.total / 4 + 1024;
     }
-    if (total == 0) return finish(dst);
 
     // 3. the planes, in one group
-    if (src) src->wait_on(cm->stream);
-    ncclResult_t r = ncclGroupStart();
-    for (int peer = 0; peer < W && r == ncclSuccess; peer++) {
-        if (peer == cm->rank && !loopback) continue;
-        if (n_me) {
-            r = ncclSend(src->x(), n_me, ncclFloat32, peer, cm->comm, cm->stream);
-            if (r == ncclSuccess) r = ncclSend(src->y(), n_me, ncclFloat32, peer, cm->comm, cm->stream);
-            if (r == ncclSuccess) r = ncclSend(src->z(), n_me, ncclFloat32, peer, cm->comm, cm->stream);
-            if (r == ncclSuccess) r = ncclSend(src->rgbt(), n_me, ncclUint32, peer, cm->comm, cm->stream);
+    if (!plan.sends.empty() || !plan.recvs.empty()) {
+        if (src) src->wait_on(cm->stream);
+        ncclResult_t r = ncclGroupStart();
+        // per pair of ranks the messages match in order: x, y, z, rgbt
+        for (const xplan::Transfer &t : plan.sends) {
+            if (r == ncclSuccess) r = ncclSend(src->x(), t.n, ncclFloat32, t.peer, cm->comm, cm->stream);
+            if (r == ncclSuccess) r = ncclSend(src->y(), t.n, ncclFloat32, t.peer, cm->comm, cm->stream);
+            if (r == ncclSuccess) r = ncclSend(src->z(), t.n, ncclFloat32, t.peer, cm->comm, cm->stream);
+            if (r == ncclSuccess) r = ncclSend(src->rgbt(), t.n, ncclUint32, t.peer, cm->comm, cm->stream);
         }
-        const size_t n = all[peer].count, at = disp[peer];
-        if (n && r == ncclSuccess) {
-            r = ncclRecv(dst->x() + at, n, ncclFloat32, peer, cm->comm, cm->stream);
-            if (r == ncclSuccess) r = ncclRecv(dst->y() + at, n, ncclFloat32, peer, cm->comm, cm->stream);
-            if (r == ncclSuccess) r = ncclRecv(dst->z() + at, n, ncclFloat32, peer, cm->comm, cm->stream);
-            if (r == ncclSuccess) r = ncclRecv(dst->rgbt() + at, n, ncclUint32, peer, cm->comm, cm->stream);
+        for (const xplan::Transfer &t : plan.recvs) {
+            if (r == ncclSuccess) r = ncclRecv(dst->x() + t.offset, t.n, ncclFloat32, t.peer, cm->comm, cm->stream);
+            if (r == ncclSuccess) r = ncclRecv(dst->y() + t.offset, t.n, ncclFloat32, t.peer, cm->comm, cm->stream);
+            if (r == ncclSuccess) r = ncclRecv(dst->z() + t.offset, t.n, ncclFloat32, t.peer, cm->comm, cm->stream);
+            if (r == ncclSuccess) r = ncclRecv(dst->rgbt() + t.offset, t.n, ncclUint32, t.peer, cm->comm, cm->stream);
+        }
+        ncclResult_t r_end = ncclGroupEnd();
+        if (r == ncclSuccess) r = r_end;
+        if (r != ncclSuccess) {
+            nccl_failed(r, "ncclSend/ncclRecv group", nullptr);
+            (void)hipStreamSynchronize(cm->stream);   // `dst` goes back to the pool
+            return none;
         }
     }
-    ncclResult_t r_end = ncclGroupEnd();
-    if (r == ncclSuccess) r = r_end;
-    if (r != ncclSuccess) {
-        nccl_failed(r, "ncclSend/ncclRecv group", nullptr);
-        (void)hipStreamSynchronize(cm->stream);   // `dst` goes back to the pool
-        return none;
-    }
-    if (n_me && !loopback) {
-        k::JoinPart part{src->x(), src->y(), src->z(), src->rgbt(), n_me, disp[cm->rank]};
+    if (plan.own_copy) {
+        k::JoinPart part{src->x(), src->y(), src->z(), src->rgbt(), src->npoints, plan.disp[cm->rank]};
         k::join_copy(part, *dst, cm->stream);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) {
             hip_failed(e, who, __FILE__, __LINE__);
@@ -299,8 +348,9 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
             return none;
         }
     }
-    if (src) src->note_reader(cm->stream);   // the sends (and the copy) are still reading the input
-    dst->mark_pending(cm->stream);
+    if (src && (!plan.sends.empty() || plan.own_copy)) src->note_reader(cm->stream);   // the sends (and the copy) are still reading the input
+    if (plan.share_input) return finish(src);   // all points are this rank's own: the result holds its planes (cwipc_hip_join_multi's rule)
+    if (dst) dst->mark_pending(cm->stream);
     return finish(dst);
 }
 
@@ -381,4 +431,27 @@ extern "C" cwipc_pointcloud *cwipc_hip_comm_submit(cwipc_hip_comm *cm, cwipc_poi
     }
     cm->queue_cv.notify_one();
     return rv;
+}
+
+// Test hook (pure host code, no device): the plan of one rank for a frame, see hip_ext.h.
+extern "C" int cwipc_hip_exchange_plan(int rank, int nranks, const uint32_t *metas, int loopback, uint64_t *summary, uint64_t *sends, uint64_t *recvs, int cap) {
+    if (metas == nullptr || summary == nullptr || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+    static_assert(sizeof(xplan::FrameMeta) == 8 * sizeof(uint32_t), "records are 8 words");
+    const xplan::FrameMeta *all = reinterpret_cast<const xplan::FrameMeta *>(metas);
+    const xplan::FramePlan plan = xplan::plan_frame(rank, nranks, all, loopback != 0);
+    uint32_t cs_bits;
+    memcpy(&cs_bits, &plan.cs_min, 4);
+    summary[0] = plan.total;
+    summary[1] = (plan.too_big ? 1u : 0u) | (plan.no_result ? 2u : 0u) | (plan.share_input ? 4u : 0u) | (plan.own_copy ? 8u : 0u) | (plan.any ? 16u : 0u) |
+                 (xplan::needs_second_round(nranks, all, loopback != 0) ? 32u : 0u) | (xplan::needs_buffer(rank, nranks, all, loopback != 0) ? 64u : 0u);
+    summary[2] = plan.ts_min;
+    summary[3] = cs_bits;
+    summary[4] = plan.disp[rank];
+    summary[5] = plan.sends.size();
+    summary[6] = plan.recvs.size();
+    summary[7] = 0;
+    if ((int)plan.sends.size() > cap || (int)plan.recvs.size() > cap) return -2;
+    for (size_t i = 0; i < plan.sends.size() && sends; i++) { sends[3 * i] = plan.sends[i].peer; sends[3 * i + 1] = plan.sends[i].n; sends[3 * i + 2] = plan.sends[i].offset; }
+    for (size_t i = 0; i < plan.recvs.size() && recvs; i++) { recvs[3 * i] = plan.recvs[i].peer; recvs[3 * i + 1] = plan.recvs[i].n; recvs[3 * i + 2] = plan.recvs[i].offset; }
+    return 0;
 }

@@ -68,7 +68,9 @@ _CWIPC_UTIL_EXPORT int cwipc_hip_comm_nranks(cwipc_hip_comm *comm);
 /* Every rank calls this once per frame with its cloud (NULL: no tile this frame) and gets the fused cloud: the ranks' points in
  * rank order, timestamp and cellsize the minimum over the clouds that took part (src/cwipc_filters.cpp:411-414).  One
  * ncclAllGather of 32 bytes per rank, then one group of ncclSend/ncclRecv that moves the planes straight into the result; the
- * call returns when the group is enqueued (the result carries an event).  NULL on error (logged). */
+ * call returns when the group is enqueued (the result carries an event).  NULL on error (logged).  What a single rank finds
+ * out on its own (no usable device, no memory for the fused cloud) travels in its record, so the others leave it out instead
+ * of waiting for it; a rank whose tile is the whole frame gets its own planes back and still sends them to the others. */
 #define CWIPC_HIP_JOIN_LOOPBACK 1   /* this rank's own part travels through RCCL too (send/recv to itself): exercises the exchange on one GPU */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *comm, cwipc_pointcloud *pc, int flags);
 /* The same for a stream of frames: returns at once with a cloud that stands for the fused cloud of this frame; the exchange
@@ -78,6 +80,16 @@ _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_join(cwipc_hip_comm *comm, c
  * order.  The argument may be freed as soon as the call returns.  A failed exchange shows as an empty cloud plus the logged
  * error.  cwipc_hip_comm_free waits for the frames still queued. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_submit(cwipc_hip_comm *comm, cwipc_pointcloud *pc, int flags);
+
+/* Test hook, pure host code (works without a GPU): the plan rank `rank` of `nranks` follows for a frame whose gathered records are
+ * `metas` (nranks x 8 uint32: count, has_cloud, cellsize bits, status [0 ok, 1 absent, 2 sends but cannot receive], ts_lo, ts_hi,
+ * capacity, 0) -- the very function cwipc_hip_comm_join issues its ncclSend / ncclRecv from (csrc/exchange_plan.hpp).
+ * summary[8] = total points, flags (1 too big, 2 no result on this rank, 4 result = this rank's input, 8 own part by copy kernel,
+ * 16 some tile arrived, 32 the ranks meet a second time before payload moves, 64 this rank needs a result buffer), ts_min,
+ * cellsize bits, this rank's displacement, number of sends, number of receives, 0; sends / recvs: cap x {peer, points, offset}.
+ * Returns 0, -1 bad arguments, -2 cap too small. */
+_CWIPC_UTIL_EXPORT int cwipc_hip_exchange_plan(int rank, int nranks, const uint32_t *metas, int loopback, uint64_t *summary,
+                                               uint64_t *sends, uint64_t *recvs, int cap);
 
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */
