@@ -1,0 +1,97 @@
+// Streaming-read shapes for the accumulate kernel (round 3): how fast do persistent workgroups read four 4-byte planes of
+// 10 M points, by waves per workgroup, 256-point steps in flight per wave, access pattern and workgroups per CU?
+// Each launch is timed on its own (event, launch, event, wait), inputs rotate over 4 copies (640 MB > the Infinity Cache).
+//   PAT 0: a step = 256 consecutive points, lane l <- points 4l..4l+3 (1 KiB per instruction and plane)
+//   PAT 1: a tile = 512 points in two instructions, lane l <- points 8l + 4k .. +3 (16 bytes at a stride of 32)
+//   PAT 2: a tile = 1024 points in four instructions, lane l <- points 16l + 4k .. +3 (16 bytes at a stride of 64)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <algorithm>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int WAVES, int DEPTH, int PAT>
+__global__ void __launch_bounds__(WAVES * 64) stream(const float* __restrict__ base, size_t stride, uint32_t n, uint32_t per_wg, float* out) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t lo = blockIdx.x * per_wg, hi = min(lo + per_wg, n);
+    const int npts = lo < hi ? (int)(hi - lo) : 0;
+    const int nsteps = (npts + 255) / 256;
+    const float* x = base + lo; const float* y = x + stride; const float* z = y + stride; const float* w = z + stride;
+    auto off = [&](int s) -> size_t {
+        if (PAT == 0) return (size_t)s * 256 + 4 * lane;
+        if (PAT == 1) return (size_t)(s >> 1) * 512 + 8 * lane + 4 * (s & 1);
+        return (size_t)(s >> 2) * 1024 + 16 * lane + 4 * (s & 3);
+    };
+    float4 a[DEPTH], b[DEPTH], c[DEPTH]; uint4 d[DEPTH];
+    // wave w takes steps w*G .. in groups of G consecutive steps (G = steps of one tile), then skips the other waves' groups
+    constexpr int G = PAT == 0 ? 1 : (PAT == 1 ? 2 : 4);
+    auto step_of = [&](int i) { return ((i / G) * WAVES + wave) * G + (i % G); };
+    int mine = 0;
+    { int groups = (nsteps + G - 1) / G; int mygroups = (groups - wave + WAVES - 1) / WAVES; if (mygroups < 0) mygroups = 0; mine = mygroups * G; }
+#pragma unroll
+    for (int u = 0; u < DEPTH; u++) {
+        a[u] = b[u] = c[u] = make_float4(0, 0, 0, 0); d[u] = make_uint4(0, 0, 0, 0);
+        if (u < mine) { const size_t o = off(step_of(u)); a[u] = *(const float4*)(x + o); b[u] = *(const float4*)(y + o); c[u] = *(const float4*)(z + o); d[u] = *(const uint4*)(w + o); }
+    }
+    float acc = 0;
+    for (int i = 0; i < mine; i += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; u++) {
+            acc += a[u].x + a[u].y + a[u].z + a[u].w + b[u].x + b[u].y + b[u].z + b[u].w + c[u].x + c[u].y + c[u].z + c[u].w + __uint_as_float((d[u].x ^ d[u].y ^ d[u].z ^ d[u].w) & 0x3fffffff);
+            const int nx = i + u + DEPTH;
+            if (nx < mine) { const size_t o = off(step_of(nx)); a[u] = *(const float4*)(x + o); b[u] = *(const float4*)(y + o); c[u] = *(const float4*)(z + o); d[u] = *(const uint4*)(w + o); }
+        }
+    }
+    if (acc == 1.2345f) { out[0] = acc; lds[threadIdx.x] = acc; }
+}
+
+static float* buf[4]; static float* out; static size_t stride; static uint32_t n = 9998244;
+
+template <int WAVES, int DEPTH, int PAT>
+void run(int blocks, int lds_bytes, const char* what) {
+    auto k = stream<WAVES, DEPTH, PAT>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    const uint32_t tile = 1024;
+    uint32_t per_wg = ((n + blocks - 1) / blocks + tile - 1) / tile * tile;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> t;
+    for (int i = 0; i < 24; i++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(WAVES * 64), lds_bytes, 0, buf[i % 4], stride, n, per_wg, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 4) t.push_back(ms * 1000);
+    }
+    std::sort(t.begin(), t.end());
+    printf("%-44s waves %2d depth %d pat %d blocks %4d lds %3d KB: median %.1f us (min %.1f)  %.2f TB/s\n", what, WAVES, DEPTH, PAT, blocks, lds_bytes / 1024, t[t.size() / 2], t[0],
+           n * 16.0 / (t[t.size() / 2] * 1e-6) / 1e12);
+}
+
+int main() {
+    stride = ((size_t)n + 1023) / 1024 * 1024 + 4096;
+    for (int i = 0; i < 4; i++) { CK(hipMalloc(&buf[i], stride * 16)); CK(hipMemset(buf[i], 1, stride * 16)); }
+    CK(hipMalloc(&out, 64));
+    const int big = 150 * 1024, half = 76 * 1024, none = 1024;
+    run<16, 1, 0>(248, big, "round-2 shape (16 waves, 1 step ahead)");
+    run<16, 2, 0>(248, big, "16 waves, 2 steps");
+    run<16, 3, 0>(248, big, "16 waves, 3 steps");
+    run<8, 2, 0>(248, big, "8 waves, 2 steps (serial kernel now)");
+    run<8, 4, 0>(248, big, "8 waves, 4 steps");
+    run<8, 6, 0>(248, big, "8 waves, 6 steps");
+    run<8, 4, 0>(256, big, "8 waves, 4 steps, 256 blocks");
+    run<8, 4, 1>(248, big, "8 waves, 4 steps, stride 32");
+    run<8, 6, 1>(248, big, "8 waves, 6 steps, stride 32");
+    run<8, 4, 2>(248, big, "8 waves, 4 steps, stride 64");
+    run<8, 8, 2>(248, big, "8 waves, 8 steps, stride 64");
+    run<4, 4, 0>(496, half, "2 x 4 waves per CU, 4 steps");
+    run<4, 8, 0>(496, half, "2 x 4 waves per CU, 8 steps");
+    run<8, 4, 0>(496, half, "2 x 8 waves per CU, 4 steps");
+    run<8, 4, 0>(512, half, "2 x 8 waves per CU, 4 steps, 512 blocks");
+    run<8, 4, 0>(1024, none, "8 waves, 4 steps, 1024 small blocks");
+    run<4, 4, 0>(2048, none, "4 waves, 4 steps, 2048 small blocks");
+    run<16, 2, 0>(1024, none, "16 waves, 2 steps, 1024 blocks no lds");
+    return 0;
+}
