@@ -2575,6 +2575,20 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                     for (int i = 1; i < 9; i++) line += std::string(names[i]) + " " + std::to_string((double)(st[w][i] - st[w][0]) * 0.01).substr(0, 5) + "; ";
                     cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", line);
                 }
+                static unsigned long long wt[1024][4];
+                if (hipMemcpyFromSymbol(wt, HIP_SYMBOL(g_wg_times), sizeof(wt)) == hipSuccess && fast_blocks > 0 && fast_blocks <= 1024) {
+                    unsigned long long t0 = ~0ull, s_max = 0, e_min = ~0ull, e_max = 0, d_min = ~0ull, d_max = 0, a_max = 0;
+                    for (uint32_t b = 0; b < fast_blocks; b++) {
+                        t0 = std::min(t0, wt[b][0]); s_max = std::max(s_max, wt[b][0]);
+                        e_min = std::min(e_min, wt[b][3]); e_max = std::max(e_max, wt[b][3]);
+                        d_min = std::min(d_min, wt[b][3] - wt[b][0]); d_max = std::max(d_max, wt[b][3] - wt[b][0]);
+                        a_max = std::max(a_max, wt[b][2]);
+                    }
+                    char buf[256];
+                    snprintf(buf, sizeof(buf), "debug: %u workgroups: last start %.2f us after the first; records updated between %.2f and %.2f us; all waves done by %.2f; a workgroup lives %.2f to %.2f us",
+                             fast_blocks, (double)(s_max - t0) * 0.01, (double)(e_min - t0) * 0.01, (double)(e_max - t0) * 0.01, (double)(a_max - t0) * 0.01, (double)d_min * 0.01, (double)d_max * 0.01);
+                    cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", buf);
+                }
                 unsigned long long wd[K1_WAVES];
                 if (hipMemcpyFromSymbol(wd, HIP_SYMBOL(g_fast_wave_done), sizeof(wd)) == hipSuccess) {
                     std::string line = "debug: workgroup 0, waves done with their steps at (us):";

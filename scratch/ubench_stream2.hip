@@ -75,6 +75,9 @@ int main() {
     for (int i = 0; i < 4; i++) { CK(hipMalloc(&buf[i], stride * 16)); CK(hipMemset(buf[i], 1, stride * 16)); }
     CK(hipMalloc(&out, 64));
     const int big = 150 * 1024, half = 76 * 1024, none = 1024;
+    run<12, 2, 0>(248, 154 * 1024, "12 waves, 2 steps, 154 KB LDS");
+    run<12, 2, 0>(248, 1024, "12 waves, 2 steps, no LDS");
+    run<12, 2, 0>(744, 1024, "12 waves, 2 steps, no LDS, 744 blocks");
     run<16, 1, 0>(248, big, "round-2 shape (16 waves, 1 step ahead)");
     run<16, 2, 0>(248, big, "16 waves, 2 steps");
     run<16, 3, 0>(248, big, "16 waves, 3 steps");
