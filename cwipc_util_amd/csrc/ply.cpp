@@ -96,7 +96,10 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
             format = fmt == "ascii" ? 0 : fmt == "binary_little_endian" ? 1 : fmt == "binary_big_endian" ? 2 : -1;
         } else if (word == "element") {
             PlyElement e;
-            is >> e.name >> e.count;
+            long long count = -1;
+            is >> e.name >> count;
+            if (is.fail() || count < 0) { why = "bad element line: " + line; return false; }   // (a count that does not parse must not read as an empty element)
+            e.count = (size_t)count;
             elements.push_back(e);
         } else if (word == "property" && !elements.empty()) {
             PlyProperty p;
@@ -122,6 +125,14 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
     }
     if (!header_done || format < 0) { why = "malformed PLY header"; return false; }
     const bool swap = (format == 1) != host_is_little_endian() && format != 0;
+    // what is left of the file bounds every count the header claims (a bogus "element vertex 10^18" must not become a reserve())
+    const std::streamoff data_at = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streamoff file_end = f.tellg();
+    f.seekg(data_at);
+    const size_t bytes_left = file_end > data_at ? (size_t)(file_end - data_at) : 0;
+    // a colour or tile value as a byte: clamped (converting a double that is out of range, or a NaN, to uint8_t is undefined)
+    const auto to_byte = [](double v) -> uint8_t { return !(v > 0.0) ? (uint8_t)0 : v >= 255.0 ? (uint8_t)255 : (uint8_t)v; };
     for (const PlyElement &e : elements) {
         const bool vertex = e.name == "vertex";
         int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, it = -1;
@@ -134,6 +145,9 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
         }
         if (vertex) {
             if (ix < 0 || iy < 0 || iz < 0) { why = "vertex element without x, y, z"; return false; }
+            size_t row_bytes = 0;   // the least a row can take: one byte per value in ASCII (digit + separator), the scalars' sizes in binary
+            for (const PlyProperty &pr : e.props) row_bytes += format == 0 ? 2 : (pr.is_list ? kTypes[pr.count_type].size : kTypes[pr.type].size);
+            if (row_bytes == 0 || e.count > bytes_left / row_bytes) { why = "element vertex claims more rows than the file can hold"; return false; }
             out.reserve(e.count);
         }
         std::vector<double> vals(e.props.size());
@@ -146,8 +160,9 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
                     char *end = nullptr;
                     if (e.props[i].is_list) {
                         const long cnt = strtol(p, &end, 10);
+                        if (cnt < 0) { why = "bad list length in: " + line; return false; }
                         p = end;
-                        for (long c = 0; c < cnt; c++) { (void)strtod(p, &end); p = end; }
+                        for (long c = 0; c < cnt && *p; c++) { (void)strtod(p, &end); if (end == p) break; p = end; }
                         continue;
                     }
                     vals[i] = strtod(p, &end);
@@ -159,8 +174,9 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
                     unsigned char buf[8];
                     if (e.props[i].is_list) {
                         if (!f.read((char *)buf, kTypes[e.props[i].count_type].size)) { why = "file ends inside element " + e.name; return false; }
-                        const long cnt = (long)load_scalar(buf, e.props[i].count_type, swap);
-                        f.seekg((std::streamoff)cnt * kTypes[e.props[i].type].size, std::ios::cur);
+                        const double cnt = load_scalar(buf, e.props[i].count_type, swap);
+                        if (!(cnt >= 0.0) || cnt * kTypes[e.props[i].type].size > (double)bytes_left) { why = "bad list length in element " + e.name; return false; }
+                        f.seekg((std::streamoff)((size_t)cnt * kTypes[e.props[i].type].size), std::ios::cur);
                         continue;
                     }
                     if (!f.read((char *)buf, kTypes[e.props[i].type].size)) { why = "file ends inside element " + e.name; return false; }
@@ -170,10 +186,10 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
             if (vertex) {
                 cwipc_point pt;
                 pt.x = (float)vals[ix]; pt.y = (float)vals[iy]; pt.z = (float)vals[iz];
-                pt.r = ir >= 0 ? (uint8_t)vals[ir] : 0;
-                pt.g = ig >= 0 ? (uint8_t)vals[ig] : 0;
-                pt.b = ib >= 0 ? (uint8_t)vals[ib] : 0;
-                pt.tile = it >= 0 ? (uint8_t)vals[it] : 0;
+                pt.r = ir >= 0 ? to_byte(vals[ir]) : 0;
+                pt.g = ig >= 0 ? to_byte(vals[ig]) : 0;
+                pt.b = ib >= 0 ? to_byte(vals[ib]) : 0;
+                pt.tile = it >= 0 ? to_byte(vals[it]) : 0;
                 out.push_back(pt);
             }
         }
@@ -233,7 +249,13 @@ extern "C" cwipc_pointcloud *cwipc_read(const char *filename, uint64_t timestamp
     if (api_version_rejected("cwipc_read", apiVersion, errorMessage)) return nullptr;
     std::vector<cwipc_point> pts;
     std::string why;
-    if (filename == nullptr || !read_ply(filename, pts, why)) {
+    bool read_ok = false;
+    try {   // (no exception crosses the C boundary: an allocation failure inside the reader is a failed load like any other)
+        read_ok = filename != nullptr && read_ply(filename, pts, why);
+    } catch (const std::exception &e) {
+        why = e.what();
+    }
+    if (!read_ok) {
         fail("cwipc_read", std::string("Loading of PLY file failed: ") + (filename ? filename : "(null)") + (why.empty() ? "" : " (" + why + ")"), errorMessage);
         return nullptr;
     }

@@ -218,7 +218,7 @@ static int radix_sort_kv32(kv32 *a, size_t n) {
 /* Returns #outputs (>=0), -2 on index overflow, -3 if cap is too small, -4 on OOM.
  * `sel` (optional) selects and orders the input points (a leaf's index vector). */
 static long voxelgrid_filter(const oracle_point *pts, const uint32_t *sel, size_t n, float leaf,
-                             oracle_point *out, size_t cap) {
+                             oracle_point *out, size_t cap, double *audit_mean, uint32_t *audit_count) {
     if (n == 0) return 0;
     /* setLeafSize: inverse_leaf_size_ = 1 / leaf_size_ (fp32). */
     const float inv = 1.0f / leaf;
@@ -287,6 +287,15 @@ static long voxelgrid_filter(const oracle_point *pts, const uint32_t *sel, size_
             tile_or |= p->tile;
         }
         size_t cnt = i - index;
+        if (audit_mean) {   /* test aid, not part of the reference: the voxel's mean in double, and its population */
+            double ax = 0, ay = 0, az = 0;
+            for (size_t li = index; li < i; li++) {
+                const oracle_point *p = &pts[iv[li].val];
+                ax += (double)p->x; ay += (double)p->y; az += (double)p->z;
+            }
+            audit_mean[3 * total + 0] = ax / (double)cnt; audit_mean[3 * total + 1] = ay / (double)cnt; audit_mean[3 * total + 2] = az / (double)cnt;
+        }
+        if (audit_count) audit_count[total] = (uint32_t)cnt;
         oracle_point *o = &out[total];
         o->x = sx / (float)cnt;
         o->y = sy / (float)cnt;
@@ -303,12 +312,16 @@ static long voxelgrid_filter(const oracle_point *pts, const uint32_t *sel, size_
 }
 
 /* src/cwipc_filters.cpp:30-87 */
+/* Test aid (oracle_downsample_audit): where the per-output double means and populations go, if anybody wants them. */
+static __thread double *g_audit_mean;
+static __thread uint32_t *g_audit_count;
+
 long oracle_downsample_voxelgrid(const oracle_point *in, size_t n, float pc_cellsize, float cellsize,
                                  oracle_point *out, size_t cap, float *out_cellsize) {
     /* :42-46 */
     if (pc_cellsize >= cellsize) cellsize = pc_cellsize;
     if (out_cellsize) *out_cellsize = cellsize;
-    long m = voxelgrid_filter(in, NULL, n, cellsize, out, cap);
+    long m = voxelgrid_filter(in, NULL, n, cellsize, out, cap, g_audit_mean, g_audit_count);
     if (m == 0) return -1; /* :58-62 "VoxelGrid filter produced empty pointcloud" -> NULL */
     return m;
 }
@@ -511,12 +524,26 @@ rebuild:
     long total = 0;
     for (size_t o = 0; o < nleaf; o++) {
         const oleaf *L = &leaves[order[o]];
-        long got = voxelgrid_filter(in, &bucket[L->first], L->count, cellsize, out + total, cap - (size_t)total);
+        long got = voxelgrid_filter(in, &bucket[L->first], L->count, cellsize, out + total, cap - (size_t)total,
+                                    g_audit_mean ? g_audit_mean + 3 * total : NULL, g_audit_count ? g_audit_count + total : NULL);
         if (got < 0) { total = got; break; }
         total += got;
     }
     free(keys); free(pidx); free(leaf_of); free(leaves); free(bucket); free(order);
     return total;
+}
+
+/* cwipc_downsample (either sign of cellsize) plus, per output, the mean of its contributors in DOUBLE and their number.
+ * Not part of the reference: it lets the tests say how far the fp32 running sums of pcl::VoxelGrid (what `out` holds) and the
+ * HIP path each are from the exact mean.  mean64: cap x 3 doubles, count: cap words. */
+long oracle_downsample_audit(const oracle_point *in, size_t n, float pc_cellsize, float cellsize,
+                             oracle_point *out, size_t cap, float *out_cellsize, double *mean64, uint32_t *count) {
+    g_audit_mean = mean64;
+    g_audit_count = count;
+    long m = oracle_downsample(in, n, pc_cellsize, cellsize, out, cap, out_cellsize, NULL, NULL);
+    g_audit_mean = NULL;
+    g_audit_count = NULL;
+    return m;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -71,6 +71,11 @@ long oracle_downsample(const oracle_point *in, size_t n, float pc_cellsize, floa
                        oracle_point *out, size_t cap, float *out_cellsize,
                        int *n_leaves, int *depth);
 
+/* Test aid, not part of the reference: oracle_downsample plus, per output, the mean of its contributors in double
+ * (mean64: cap x 3) and their number (count: cap). */
+long oracle_downsample_audit(const oracle_point *in, size_t n, float pc_cellsize, float cellsize,
+                             oracle_point *out, size_t cap, float *out_cellsize, double *mean64, uint32_t *count);
+
 /* ---- statistical outlier removal: src/cwipc_filters.cpp:181-278 + pcl::StatisticalOutlierRemoval ----
  * Returns number of kept points (written to out in order), or -1 on error.
  * mean_dist (optional, n floats; perTile=0 only) receives d_i; thr (optional) the threshold. */

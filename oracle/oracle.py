@@ -63,6 +63,8 @@ def load(native: bool = False) -> ctypes.CDLL:
     lib.oracle_downsample_voxelgrid.restype = ctypes.c_long
     lib.oracle_downsample.argtypes = [P, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, P, ctypes.c_size_t, P, P, P]
     lib.oracle_downsample.restype = ctypes.c_long
+    lib.oracle_downsample_audit.argtypes = [P, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, P, ctypes.c_size_t, P, P, P]
+    lib.oracle_downsample_audit.restype = ctypes.c_long
     lib.oracle_remove_outliers.argtypes = [P, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int, P, P, P]
     lib.oracle_remove_outliers.restype = ctypes.c_long
     lib.oracle_knn_mean_dist.argtypes = [P, ctypes.c_size_t, ctypes.c_int, P]
@@ -167,6 +169,21 @@ def downsample(pts: np.ndarray, pc_cellsize: float, cellsize: float, info: Optio
         info['n_leaves'] = nl.value
         info['depth'] = dp.value
     return out[:m].copy(), float(ocs.value)
+
+
+def downsample_audit(pts: np.ndarray, pc_cellsize: float, cellsize: float):
+    """downsample() plus, per output, the float64 mean of its contributors (m x 3) and their number (m): how far pcl's fp32
+    running sums and the HIP path each are from the exact mean is then a matter of arithmetic, not of trust."""
+    pts = _pts(pts)
+    out = empty(max(len(pts), 1))
+    mean64 = np.zeros((max(len(pts), 1), 3), dtype=np.float64)
+    count = np.zeros(max(len(pts), 1), dtype=np.uint32)
+    ocs = ctypes.c_float(0)
+    m = load().oracle_downsample_audit(_p(pts), len(pts), pc_cellsize, cellsize, _p(out), len(out), ctypes.addressof(ocs),
+                                       mean64.ctypes.data, count.ctypes.data)
+    if m < 0:
+        raise OracleError(f"downsample: reference returns NULL (code {m})")
+    return out[:m].copy(), float(ocs.value), mean64[:m].copy(), count[:m].copy()
 
 
 def remove_outliers(pts: np.ndarray, k: int, stddev_mul: float, per_tile: bool,

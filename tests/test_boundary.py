@@ -188,6 +188,28 @@ def test_ply_errors_are_loud(cwipc, tmp_path):
     open(short, "w").write("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n")
     with pytest.raises(cwipc.CwipcError):
         cwipc.cwipc_read(short, 0)
+    # a header that lies: a vertex count no file could hold, one that does not parse, a negative list length -- a failed
+    # load with a message each, never an exception through the C boundary or a seek backwards
+    hdr = "ply\nformat %s 1.0\nelement vertex %s\nproperty float x\nproperty float y\nproperty float z\n%send_header\n"
+    for name, text in (("huge", hdr % ("ascii", "1000000000000000000", "") + "1 2 3\n"),
+                       ("nan_count", hdr % ("ascii", "many", "") + "1 2 3\n"),
+                       ("negative", hdr % ("ascii", "-5", "") + "1 2 3\n")):
+        fn = str(tmp_path / (name + ".ply"))
+        open(fn, "w").write(text)
+        with pytest.raises(cwipc.CwipcError):
+            cwipc.cwipc_read(fn, 0)
+    fn = str(tmp_path / "neglist.ply")
+    with open(fn, "wb") as f:
+        f.write((hdr % ("binary_little_endian", "1", "property list int int idx\n")).encode())
+        f.write(struct.pack("<fffi", 1, 2, 3, -7))
+    with pytest.raises(cwipc.CwipcError):
+        cwipc.cwipc_read(fn, 0)
+    # colours out of range and not-a-number are clamped, not converted with undefined behaviour
+    fn = str(tmp_path / "clamp.ply")
+    open(fn, "w").write("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nproperty float red\n"
+                        "property float green\nproperty float blue\nproperty float alpha\nend_header\n1 2 3 300 -4 nan 7\n4 5 6 1e30 0.9 255 256\n")
+    a = cwipc.cwipc_read(fn, 0).get_numpy_array()
+    assert [tuple(int(v) for v in (p['r'], p['g'], p['b'], p['tile'])) for p in a] == [(255, 0, 0, 7), (255, 0, 255, 255)]
 
 
 def test_debugdump(cwipc, tmp_path):

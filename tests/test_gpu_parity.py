@@ -324,36 +324,60 @@ def voxel_population(pts, leaf, out):
     return np.where(uniq[pos] == k, cnt[pos], len(pts))
 
 
+TOLERANCE_USED = {}   # what the downsample checks measured, by (points, cellsize): printed at the end of the session (conftest) and asserted below
+
+
 def check_downsample(gpu, oracle, pts, pc_cellsize, cellsize, ordered=True):
     pc = make_cloud(gpu, pts, pc_cellsize, 4242)
     out = gpu.cwipc_downsample(pc, cellsize)
-    exp, exp_cs = oracle.downsample(pts, pc_cellsize, cellsize)
+    exp, exp_cs, mean64, count = oracle.downsample_audit(pts, pc_cellsize, cellsize)
     got = out.get_numpy_array()
     assert len(got) == len(exp), (len(got), len(exp))
     assert out.timestamp() == 4242
     assert out.cellsize() == pytest.approx(exp_cs, rel=0, abs=0)
     if not ordered:
-        got = np.sort(got, order=['z', 'y', 'x'])
-        exp = np.sort(exp, order=['z', 'y', 'x'])
-    # The bar is 1e-5 wherever a voxel holds at most a few hundred points (the typical voxel of every
+        order_g, order_e = np.argsort(got, order=['z', 'y', 'x']), np.argsort(exp, order=['z', 'y', 'x'])
+        got, exp, mean64, count = got[order_g], exp[order_e], mean64[order_e], count[order_e]
+    # The bar is north_star's 1e-5 wherever a voxel holds at most a few hundred points (the typical voxel of every
     # BASELINE configuration: 254 points on average at 10 M).  The reference algorithm keeps an fp32
     # running sum per voxel (pcl AccumulatorXYZ), whose own rounding error grows with the number of
-    # points in the voxel; the HIP path sums exact integers and rounds once (see
-    # test_downsample_means_are_correctly_rounded).  For crowded voxels (coarse cells, or the apex of
-    # the synthetic shape where whole rows collapse into one voxel) the bound widens per voxel with
-    # that error model.
+    # points in the voxel; the HIP path sums exact integers and rounds once.  For crowded voxels (coarse cells, or the apex of
+    # the synthetic shape where whole rows collapse into one voxel) the bound on |HIP - oracle| widens per voxel with
+    # that error model -- and what is USED of it is measured: the oracle also hands out every output's mean in float64
+    # (oracle_downsample_audit; not part of the reference), against which the HIP path must stay within
+    # leaf * 2^-22 + 1.5 ulp whatever the population (the fp32 product p * inv_leaf costs half an ulp of the coordinate, the
+    # offset inside the voxel 2^-23 of a voxel, the final rounding to fp32 half an ulp).
     if len(exp):
         fin = np.isfinite(pts['x']) & np.isfinite(pts['y']) & np.isfinite(pts['z'])   # the filter skips the others
-        pop = voxel_population(pts[fin], max(abs(cellsize), pc_cellsize), exp)
+        pop = count.astype(np.int64)
         maxabs = max(float(np.abs(pts[f][fin]).max()) for f in ('x', 'y', 'z')) if fin.any() else 0.0
         # (the same model covers clouds far from the origin: the oracle's running sums lose sqrt(pop) ulps of the
         # coordinate magnitude; the strict bar applies where BASELINE lives: |coordinates| <= 4, <= 300 points per voxel)
         model = np.maximum(XYZ_TOL, 4.0 * np.sqrt(pop) * float(np.spacing(np.float32(maxabs))))
         tol = np.where((pop <= 300) & (maxabs <= 4.0), XYZ_TOL, model)
-        for f in ('x', 'y', 'z'):
-            err = np.abs(got[f].astype(np.float64) - exp[f].astype(np.float64))
+        leaf = float(max(abs(cellsize), pc_cellsize))
+        used = {"outputs": int(len(exp)), "outputs_above_300_points": int((pop > 300).sum()), "largest_population": int(pop.max())}
+        for i, f in enumerate(('x', 'y', 'z')):
+            g = got[f].astype(np.float64)
+            err = np.abs(g - exp[f].astype(np.float64))
             worst = int(np.argmax(err - tol))
             assert (err <= tol).all(), (f, float(err[worst]), float(tol[worst]), int(pop[worst]))
+            # against the exact mean: the HIP path everywhere, the oracle's fp32 sums for comparison
+            e64 = np.abs(g - mean64[:, i])
+            bound = leaf * 2.0 ** -22 + 1.5 * np.spacing(np.abs(mean64[:, i]).astype(np.float32)).astype(np.float64)
+            w64 = int(np.argmax(e64 - bound))
+            assert (e64 <= bound).all(), ("HIP vs float64 mean", f, float(e64[w64]), float(bound[w64]), int(pop[w64]))
+            small = pop <= 300
+            used.setdefault("hip_vs_oracle_max_pop_le_300", 0.0)
+            used.setdefault("hip_vs_oracle_max_pop_gt_300", 0.0)
+            used.setdefault("hip_vs_f64_mean_max", 0.0)
+            used.setdefault("oracle_vs_f64_mean_max", 0.0)
+            if small.any(): used["hip_vs_oracle_max_pop_le_300"] = max(used["hip_vs_oracle_max_pop_le_300"], float(err[small].max()))
+            if (~small).any(): used["hip_vs_oracle_max_pop_gt_300"] = max(used["hip_vs_oracle_max_pop_gt_300"], float(err[~small].max()))
+            used["hip_vs_f64_mean_max"] = max(used["hip_vs_f64_mean_max"], float(e64.max()))
+            used["oracle_vs_f64_mean_max"] = max(used["oracle_vs_f64_mean_max"], float(np.abs(exp[f].astype(np.float64) - mean64[:, i]).max()))
+        TOLERANCE_USED[(len(pts), float(cellsize))] = used
+        print("downsample tolerance used: %d points, cellsize %g: %s" % (len(pts), cellsize, used))
     for f in ('r', 'g', 'b', 'tile'):
         assert (got[f] == exp[f]).all(), f
     return got, exp
@@ -1040,6 +1064,15 @@ def test_full_size_downsample(gpu, oracle, full_cloud):
         assert np.abs(again[f] - got[f]).max() <= 2.4e-7
         assert pts[f].min() <= got[f].min() and got[f].max() <= pts[f].max()
     assert (again['tile'] == got['tile']).all() and (again['r'] == got['r']).all()
+    # what the widened bar uses at BASELINE configs[1] (VERDICT round 2, weak point 1): on record for DESIGN section 4
+    used = {"%d points, cellsize %g" % k: v for k, v in TOLERANCE_USED.items() if k[0] == len(pts)}
+    octree = TOLERANCE_USED[(len(pts), 0.01)]
+    assert octree["hip_vs_oracle_max_pop_le_300"] <= XYZ_TOL and octree["hip_vs_f64_mean_max"] <= 3.0e-7
+    import json, os
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(outdir):
+        with open(os.path.join(outdir, "tolerance_used.json"), "w") as f:
+            json.dump(used, f, indent=1)
 
 
 def test_full_size_downsample_is_order_independent(gpu, full_cloud):
