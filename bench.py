@@ -181,12 +181,17 @@ def bench_config4(cwipc, rank: int, world: int, steps: int, warmup: int, fence, 
         local = cwipc.cwipc_join_multi(outs) if outs else None
         return join_across_ranks(local) if join_across_ranks is not None else local
 
+    fused = None
     for _ in range(warmup):
-        frame()
+        fused = frame()
+    if fused is not None:
+        fused.count()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         fused = frame()
+    if fused is not None:
+        fused.count()   # (a submitted join settles here: this frame's exchange, and every earlier one's, has been issued)
     fence()
     elapsed = time.perf_counter() - t0
     if pool is not None:
@@ -484,8 +489,10 @@ def main() -> None:
     if not args.no_config4:
         if joiner is not None:
             joiner.drain()
-        c4_elapsed, c4_ntile, c4_fused, c4_mine, c4_threads = bench_config4(cwipc, rank, world, args.config4_steps, 3, fence,
-                                                                join_across_ranks if joining else None)
+        # (N > 1 with the library's exchange: cwipc_hip_comm_submit, so that the join of frame i overlaps the tiles of frame i + 1;
+        # the last frame's fused cloud is settled -- every exchange has then been issued -- before the clock stops)
+        c4_join = (lib_comm.submit if lib_comm is not None else join_across_ranks) if joining else None
+        c4_elapsed, c4_ntile, c4_fused, c4_mine, c4_threads = bench_config4(cwipc, rank, world, args.config4_steps, 3, fence, c4_join)
         if dist is not None:
             t = torch.tensor([c4_elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -64,7 +64,7 @@ std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, 
     size_t n = src.npoints;
     if (n == 0) return soa_alloc(0);
     size_t nb = k::compact_blocks(n);
-    uint32_t *counts = (uint32_t *)c.device_scratch(nb * sizeof(uint32_t));
+    uint32_t *counts = (uint32_t *)c.device_scratch((nb + 1) * sizeof(uint32_t));   // (+ the total, for the scatter kernel)
     auto dst = soa_alloc(n);
     if (!counts || !dst) return nullptr;
     // the scan kernel publishes the kept count with this tag in the upper half of the first 64-bit pinned word
@@ -98,6 +98,19 @@ std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, 
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_hip", "compaction: inconsistent count");
         if (seen) (void)c.sync();
         return nullptr;
+    }
+    if (kept == n) {
+        // every point kept: the result holds the input's planes (clouds are immutable); the scatter kernel saw the same total
+        // and copied nothing.  (The input is complete: the count kernel, ordered behind its producer, has run.)
+        auto same = std::make_shared<DeviceSoA>();
+        same->xyz_block = src.xyz_block;
+        same->rgbt_block = src.rgbt_block;
+        same->npoints = src.npoints;
+        same->stride = src.stride;
+        same->device = src.device;
+        if (src.has_first) { same->first[0] = src.first[0]; same->first[1] = src.first[1]; same->first[2] = src.first[2]; same->has_first = true; }
+        // (`dst` goes back to the pool untouched: the scatter kernel writes nothing)
+        return same;
     }
     if (kept * 16 >= n) {
         dst->npoints = kept;   // the planes keep their spacing (stride), only the count shrinks

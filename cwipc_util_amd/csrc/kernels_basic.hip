@@ -215,7 +215,10 @@ __global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict
         if (threadIdx.x == 1023) carry = c + wave_base + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) __hip_atomic_store(total, ((unsigned long long)tag << 32) | carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        counts[nblocks] = carry;   // for the scatter kernel: a compaction that keeps every point moves nothing
+        __hip_atomic_store(total, ((unsigned long long)tag << 32) | carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
@@ -223,6 +226,9 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
                                                                const uint32_t *__restrict__ block_offsets, float *__restrict__ ox,
                                                                float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
     __shared__ uint32_t wave_sum[STEPS][WAVES];
+    // every point kept (a tile filter on a cloud of that one tile, a crop box around everything): the host hands the input's
+    // planes on as the result, nothing is copied
+    if (block_offsets[gridDim.x] == n) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile0 = (size_t)blockIdx.x * TILE;
     const size_t out0 = block_offsets[blockIdx.x];
