@@ -35,7 +35,8 @@ CPU oracle (a single-threaded C restatement of the PCL algorithm, NOT PCL) on th
 core, and (`all_cores`) every core of the host running one cloud each.  Sub-records in the same line: `config4` =
 BASELINE configs[3], the 8 x 2 M-tile capture (tilefilter -> downsample per tile, n-ary join, join across ranks), tile t
 on rank t mod N, strong scaling; `config3` = BASELINE configs[2], outlier removal of the 10 M cloud (N = 1 only), with its
-own roofline fraction over all kernels of a call.
+own roofline fraction over all kernels of a call; `config5` = BASELINE configs[4], the live-size stream (8 x 300 k-point tiles per
+frame through colorize -> downsample -> outliers -> join, >= 300 frames: frames/s, p50 / p99 frame latency, what PCIe adds).
 """
 from __future__ import annotations
 
@@ -199,6 +200,82 @@ def bench_config4(cwipc, rank: int, world: int, steps: int, warmup: int, fence, 
     return elapsed, n_tile, (fused.count() if fused is not None else 0), len(mine), nthreads
 
 
+def bench_config5(cwipc, rank: int, world: int, frames: int, warmup: int, fence, join_across_ranks):
+    """BASELINE configs[4]: the live-size stream.  Per frame 8 tiles x synthetic(300 000) (the capture of config 4 at a tenth
+    of the size), tile t on rank t mod world; per tile the full chain colorize(0.8, "camera") -> downsample(0.01) ->
+    remove_outliers(16, 1.0, false) (reference loop: python/cwipc/scripts/_scriptsupport.py:346-390 feeding
+    registration/util.py:91-96 and :170-182); the tiles of a rank joined (n-ary join), then the join across ranks.  A frame
+    is complete when its fused cloud's points exist (count()): that wall time is the frame's latency; frames are NOT
+    overlapped here, so fps = 1 / mean latency is the conservative figure.  Inputs resident in HBM; a second, shorter pass
+    hands host arrays in and takes the fused cloud back as a host array (what PCIe adds)."""
+    from cwipc_util_amd.capture import capture_tile
+    from cwipc_util_amd.filters.colorize import ColorizeFilter
+    from cwipc_util_amd.multigpu import tiles_of_rank
+    NT, NP = 8, 300_000
+    mine = tiles_of_rank(NT, rank, world)
+    tiles = []
+    for t in mine:
+        pc = capture_tile(NP, t, NT, timestamp=2000 + t)
+        cwipc.cwipc_hip_upload(pc, drop_host_copy=True)
+        tiles.append(pc)
+    n_tile = tiles[0].count() if tiles else 0
+    flt = ColorizeFilter(0.8, "camera")
+    nthreads = max(1, min(int(os.environ.get("CWIPC_BENCH_TILE_THREADS", "4")), len(tiles)))
+    pool = None
+    if nthreads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=nthreads)
+
+    def chain(pc):
+        pc = flt.filter(pc)
+        pc = cwipc.cwipc_downsample(pc, CELLSIZE)
+        return cwipc.cwipc_remove_outliers(pc, 16, 1.0, False)
+
+    def frame(inputs):
+        outs = list(pool.map(chain, inputs)) if pool is not None else [chain(pc) for pc in inputs]
+        local = cwipc.cwipc_join_multi(outs) if outs else None
+        fused = join_across_ranks(local) if join_across_ranks is not None else local
+        return fused
+
+    for _ in range(warmup):
+        f = frame(tiles)
+        if f is not None:
+            f.count()
+    fence()
+    lat = []
+    fused_points = 0
+    t_all = time.perf_counter()
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        f = frame(tiles)
+        fused_points = f.count() if f is not None else 0
+        lat.append(time.perf_counter() - t0)
+    fence()
+    elapsed = time.perf_counter() - t_all
+    # what PCIe adds: host arrays in, host array out (rank-local part of the chain only)
+    host_ms = None
+    if tiles and world == 1:
+        arrays = [(pc.get_numpy_array().copy(), pc.cellsize(), pc.timestamp()) for pc in tiles]
+        times = []
+        for i in range(20 + 3):
+            t0 = time.perf_counter()
+            ins = []
+            for a, cs, ts in arrays:
+                pc = cwipc.cwipc_from_numpy_array(a, ts)
+                pc._set_cellsize(cs)
+                ins.append(pc)
+            f = frame(ins)
+            f.get_numpy_array()
+            if i >= 3:
+                times.append(time.perf_counter() - t0)
+        host_ms = float(np.median(times)) * 1e3
+    if pool is not None:
+        pool.shutdown()
+    lat_ms = np.array(lat) * 1e3
+    return {"elapsed": elapsed, "n_tile": n_tile, "fused_points": fused_points, "tiles_here": len(mine), "threads": nthreads,
+            "p50_ms": float(np.percentile(lat_ms, 50)), "p99_ms": float(np.percentile(lat_ms, 99)), "host_io_ms_per_frame": host_ms}
+
+
 def bench_config3(cwipc, pc, n: int, runs: int = 5):
     """BASELINE configs[2]: cwipc_remove_outliers(k = 16, sigma = 1.0, perTile = false) on the 10 M-point cloud.
     Algorithmic bytes: 16 N + 8 N (the d_i round trip) + 16 N_keep."""
@@ -237,6 +314,8 @@ def main() -> None:
     ap.add_argument("--no-config4", action="store_true", help="skip the 8-tile capture sub-record")
     ap.add_argument("--no-config3", action="store_true", help="skip the outlier-removal sub-record (N = 1 only)")
     ap.add_argument("--config4-steps", type=int, default=30)
+    ap.add_argument("--no-config5", action="store_true", help="skip the live-size stream sub-record")
+    ap.add_argument("--config5-frames", type=int, default=300)
     args = ap.parse_args()
 
     # Exactly ONE line goes to stdout: the JSON line.  Libraries that print there on their own (RCCL writes a five-line
@@ -506,6 +585,28 @@ def main() -> None:
             "ms_per_frame": c4_elapsed / args.config4_steps * 1e3, "points_per_tile": c4_ntile, "tiles_on_rank0": c4_mine,
             "fused_points": c4_fused, "inputs_resident_in_hbm": True, "tile_threads_per_rank": c4_threads,
         }
+    config5 = None
+    if not args.no_config5:
+        c5_join = (lib_comm.submit if lib_comm is not None else join_across_ranks) if joining else None
+        c5 = bench_config5(cwipc, rank, world, args.config5_frames, 10, fence, c5_join)
+        c5_elapsed = c5["elapsed"]
+        if dist is not None:
+            t = torch.tensor([c5_elapsed, c5["p50_ms"], c5["p99_ms"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c5_elapsed, c5["p50_ms"], c5["p99_ms"] = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        ms_frame = c5_elapsed / args.config5_frames * 1e3
+        config5 = {
+            "workload": "per frame 8 x cwipc_synthetic(300000, angle = i pi/4), mask 1 << i, rotated i x 45 deg about Y; tile t on rank t mod N: "
+                        "colorize(0.8, camera) -> cwipc_downsample(0.01) -> cwipc_remove_outliers(16, 1.0, false), n-ary join"
+                        + (f", all-gatherv join over {world} ranks" if joining else "") + " [BASELINE configs[4]]",
+            "value": args.config5_frames / c5_elapsed, "unit": "frames/s", "target_frames_per_s": 30.0, "scaling": "strong", "n_gpus": world,
+            "frames": args.config5_frames, "ms_per_frame": ms_frame, "p50_ms": c5["p50_ms"], "p99_ms": c5["p99_ms"],
+            "points_per_tile": c5["n_tile"], "tiles_on_rank0": c5["tiles_here"], "fused_points": c5["fused_points"],
+            "inputs_resident_in_hbm": True, "tile_threads_per_rank": c5["threads"],
+            "frames_overlapped": False,
+            "host_arrays_in_and_out_ms_per_frame": c5["host_io_ms_per_frame"],
+            "h2d_d2h_share_of_that": (1.0 - ms_frame / c5["host_io_ms_per_frame"]) if c5["host_io_ms_per_frame"] else None,
+        }
     config3 = None
     if world == 1 and not args.no_config3 and args.npoints == NPOINTS_ARG:
         config3 = bench_config3(cwipc, clouds[0], n)
@@ -562,6 +663,8 @@ def main() -> None:
             result["config4"] = config4
         if config3 is not None:
             result["config3"] = config3
+        if config5 is not None:
+            result["config5"] = config5
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pts, pc_cellsize)
         sys.stdout.flush()

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-ARGS="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-config4 --no-config3"
+ARGS="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-config4 --no-config3 --no-config5"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/p1 -- python3 $ARGS > $OUT/p1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT/p2.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_MISC SQ_IFETCH --output-format csv -d $OUT/p3 -- python3 $ARGS > $OUT/p3.log 2>&1 || true

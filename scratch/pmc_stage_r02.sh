@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 export CWIPC_LIBRARY_DIR=$GRAFT_REPO_ROOT/scratch/lib_dbg
 for a in 0 8 9 10 12; do
   export CWIPC_FAST_DBG=$a
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $OUT/a$a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config4 --no-config3 > $OUT/a$a.log 2>&1 || exit 1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $OUT/a$a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config4 --no-config3 --no-config5 > $OUT/a$a.log 2>&1 || exit 1
 done
 python3 - <<'PY'
 import csv, glob, collections, os

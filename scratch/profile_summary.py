@@ -1,7 +1,10 @@
-"""Condense a profile_round.sh output directory into the text committed under profiles/."""
-import csv, glob, collections, sys, json, os
+"""Condense a profile_round.sh output directory into the files committed under profiles/: the summary text (stdout), and beside
+it <round>_bench_kernel_stats.csv (the very csv the summary quotes) and <round>_traffic.json (HBM bytes per launch of the
+accumulate kernel from the two PMC passes)."""
+import csv, glob, collections, sys, json, os, shutil
 out = sys.argv[1]
-print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-config4 --no-config3")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "rNN"
+print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-config4 --no-config3 --no-config5")
 for l in open(os.path.join(out, "bench_trace.json")):
     if l.startswith("{"):
         d = json.loads(l)
@@ -9,7 +12,8 @@ for l in open(os.path.join(out, "bench_trace.json")):
             d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms_avg"]))
 stats = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
 for f in stats:
-    print("## kernel_stats.csv")
+    shutil.copyfile(f, os.path.join(out, rnd + "_bench_kernel_stats.csv"))
+    print("## kernel_stats.csv (committed beside this file as %s_bench_kernel_stats.csv)" % rnd)
     rows = list(csv.DictReader(open(f)))
     print("%-70s %8s %14s %12s %12s %12s %7s" % ("Name", "Calls", "TotalNs", "AvgNs", "MinNs", "MaxNs", "Pct"))
     for r in rows:
@@ -32,3 +36,34 @@ for name in ("fetch", "write"):
         for k, v in agg.items():
             for c, x in v.items():
                 print("%-70s %s mean=%.1f n=%d" % (k[:70], c, sum(x) / len(x), len(x)))
+
+# HBM bytes per launch of the accumulate kernel (what bench.py quotes as roofline.traffic)
+means = {}
+symbol = None
+for name in ("fetch", "write"):
+    for f in glob.glob(out + f"/{name}/**/*counter_collection.csv", recursive=True):
+        vals = []
+        for row in csv.DictReader(open(f)):
+            if "voxel_accumulate" in row["Kernel_Name"] and "general" not in row["Kernel_Name"] and row["Counter_Name"] == name.upper() + "_SIZE":
+                vals.append(float(row["Counter_Value"]))
+                symbol = row["Kernel_Name"].split("(")[0].split("::")[-1]
+        if vals:
+            means[name] = sum(vals) / len(vals)
+if "fetch" in means and "write" in means:
+    n_points = None
+    for l in open(os.path.join(out, "bench_fetch.json")):
+        if l.startswith("{"):
+            n_points = json.loads(l)["config"]["points_per_gpu"]
+    rec = {
+        "round": int(rnd.lstrip("r") or 0),
+        "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-config4 --no-config3 --no-config5 ; same with --pmc WRITE_SIZE (separate passes; scratch/profile_round.sh %s)" % rnd,
+        "workload_points": n_points,
+        "kernel": "voxel_accumulate",
+        "kernel_symbol": symbol,
+        "FETCH_SIZE_KiB_raw_mean_per_dispatch": means["fetch"],
+        "WRITE_SIZE_KiB_mean_per_dispatch": means["write"],
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16 B/lane streaming loads -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is (64-bit atomics on 64-B records: uncalibrated access width)",
+        "hbm_bytes_per_launch": int(round((2 * means["fetch"] + means["write"]) * 1024)),
+    }
+    json.dump(rec, open(os.path.join(out, rnd + "_traffic.json"), "w"), indent=1)
+    print("## traffic: %d B per launch (2 x FETCH_SIZE + WRITE_SIZE) -> %s_traffic.json" % (rec["hbm_bytes_per_launch"], rnd))

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 export CWIPC_LIBRARY_DIR=$GRAFT_REPO_ROOT/scratch/lib_dbg
 export CWIPC_VOXEL_SERIAL=1
 for d in 0 8 16384 16392 1024 1032 3072 3080 4096 4104 8192 8200; do
-  CWIPC_SERIAL_DBG=$d python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-config4 --no-config3 2>/dev/null | python3 -c "
+  CWIPC_SERIAL_DBG=$d python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-config4 --no-config3 --no-config5 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('dbg', $d, 'K1 us', round(d['kernels']['voxel_accumulate']['ms_avg']*1e3,1), 'step', round(d['ms_per_step']*1e3,1))"
 done

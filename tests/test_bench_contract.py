@@ -26,3 +26,26 @@ def test_defaults_are_the_contracts():
     for needle in ('"--gpus", type=int, default=1', '"--steps", type=int, default=200', '"--warmup", type=int, default=20'):
         assert needle in src, needle
     assert 'HBM_PEAK_GBPS = 8000.0' in src
+
+
+def test_committed_profile_files_are_from_one_run():
+    """The newest round's kernel-stats csv is the one its summary text quotes (the two disagreed): the
+    accumulate kernel's AverageNs in the csv equals the figure printed in the summary, and the summary's bench line is there."""
+    import csv
+    import re
+    prof = os.path.join(ROOT, "profiles")
+    rounds = sorted({f.split("_")[0] for f in os.listdir(prof) if re.match(r"r\d\d_bench_rocprofv3_summary\.txt", f)})
+    newest = rounds[-1]
+    if int(newest[1:]) < 3:
+        import pytest
+        pytest.skip("round 2's files predate the single-run script")
+    rows = list(csv.DictReader(open(os.path.join(prof, newest + "_bench_kernel_stats.csv"))))
+    k1 = [r for r in rows if "voxel_accumulate" in r["Name"] and "general" not in r["Name"]]
+    assert len(k1) == 1, [r["Name"] for r in k1]
+    avg_csv = float(k1[0]["AverageNs"])
+    summary = open(os.path.join(prof, newest + "_bench_rocprofv3_summary.txt")).read()
+    m = re.search(r"^\S*voxel_accumulate\S*.*?\s+(\d+)\s+(\d+)\s+(\d+)\s+\d+\s+\d+\s+[\d.]+\s*$", summary, re.M)
+    assert m, "no accumulate-kernel row in the summary"
+    assert int(m.group(1)) == int(k1[0]["Calls"]) and abs(int(m.group(3)) - avg_csv) <= 1.0, (m.groups(), avg_csv)
+    assert "# bench line under the profiler:" in summary
+    assert os.path.exists(os.path.join(prof, newest + "_bench_line.json")) and os.path.exists(os.path.join(prof, newest + "_traffic.json"))
