@@ -593,6 +593,66 @@ extern "C" cwipc_pointcloud *cwipc_from_packet(uint8_t *packet, size_t size, cha
     return rv;
 }
 
+// ---------------------------------------------------------------------------
+// The proxy's wire format as a packet codec (no sockets: the transport stays the application's).
+// reference src/cwipc_proxy.cpp:179-216 (what the server reads: a 24-byte cwipc_point_packetheader, api.h:100-110, then
+// dataCount bytes of cwipc_point records; it answers with the 8 bytes of the timestamp) and
+// python/cwipc/scripts/cwipc_toproxy.py:51-57 (what the sender writes: struct.pack("<iiqfi", magic, len, timestamp, cellsize, 0)).
+// The two do not agree on the magic number -- C: 0x20201016 (api.h:110), Python: 0x20210208 (util.py:346) -- so a reference
+// sender cannot talk to a reference server (its proxy tests are skipped, test_cwipc_util.py:617-633).  Not "fixed" here: the
+// writer takes the magic it is told (default: the C one), the reader accepts the C one and, only when asked to, the Python one.
+// ---------------------------------------------------------------------------
+static_assert(sizeof(cwipc_point_packetheader) == 24, "the proxy header is 24 bytes on the wire");
+
+extern "C" size_t cwipc_hip_proxy_packet(cwipc_pointcloud *pc, uint8_t *packet, size_t size, uint32_t magic) {
+    if (pc == nullptr) return 0;
+    const size_t data = pc->get_uncompressed_size();
+    const size_t need = sizeof(cwipc_point_packetheader) + data;
+    if (packet == nullptr) return need;   // (how much room the packet takes)
+    if (size < need || data > 0xffffffffull) return 0;
+    cwipc_point_packetheader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = magic ? magic : (uint32_t)CWIPC_POINT_PACKETHEADER_MAGIC;
+    h.dataCount = (uint32_t)data;
+    h.timestamp = pc->timestamp();
+    h.cellsize = pc->cellsize();
+    memcpy(packet, &h, sizeof(h));
+    if (data && pc->copy_uncompressed(reinterpret_cast<cwipc_point *>(packet + sizeof(h)), data) < 0) return 0;
+    return need;
+}
+
+extern "C" cwipc_pointcloud *cwipc_hip_from_proxy_packet(const uint8_t *packet, size_t size, int accept_python_magic, char **errorMessage, uint64_t apiVersion) {
+    if (api_version_rejected("cwipc_hip_from_proxy_packet", apiVersion, errorMessage)) return nullptr;
+    cwipc_log_set_errorbuf(errorMessage);
+    cwipc_pointcloud *out = nullptr;
+    do {
+        cwipc_point_packetheader h;
+        if (packet == nullptr || size < sizeof(h)) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_proxy", "short packet header");
+            break;
+        }
+        memcpy(&h, packet, sizeof(h));
+        if (h.magic != (uint32_t)CWIPC_POINT_PACKETHEADER_MAGIC && !(accept_python_magic && h.magic == 0x20210208u)) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_proxy", "invalid magic number in packet header");   // (the server's words, cwipc_proxy.cpp:188)
+            break;
+        }
+        if ((size_t)h.dataCount != size - sizeof(h)) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_proxy", "packet length does not match dataCount");
+            break;
+        }
+        // as the server: cwipc_from_points(points, dataCount, dataCount / sizeof(cwipc_point), timestamp), then the cellsize (:204-213)
+        auto *rv = new cwipc_hip_pointcloud();
+        if (rv->from_points(reinterpret_cast<const cwipc_point *>(packet + sizeof(h)), h.dataCount, (int)(h.dataCount / sizeof(cwipc_point)), h.timestamp) < 0) {
+            delete rv;   // (from_points has logged "incorrect size" / ...)
+            break;
+        }
+        rv->_set_cellsize(h.cellsize);
+        out = rv;
+    } while (false);
+    cwipc_log_set_errorbuf(nullptr);
+    return out;
+}
+
 // reference src/cwipc_util.cpp:499-580 -- same 32-byte header + AoS payload as a packet.
 extern "C" cwipc_pointcloud *cwipc_read_debugdump(const char *filename, char **errorMessage, uint64_t apiVersion) {
     if (api_version_rejected("cwipc_read_debugdump", apiVersion, errorMessage)) return nullptr;

@@ -27,7 +27,7 @@ import numpy.typing
 from .abstract import cwipc_pointcloud_abstract, cwipc_source_abstract, cwipc_activesource_abstract, cwipc_tileinfo_dict
 
 __all__ = [
-    'CWIPC_API_VERSION', 'CWIPC_POINT_PACKETHEADER_MAGIC', 'CWIPC_FLAGS_BINARY', 'CwipcError',
+    'CWIPC_API_VERSION', 'CWIPC_POINT_PACKETHEADER_MAGIC', 'CWIPC_POINT_PACKETHEADER_MAGIC_C', 'cwipc_proxy_packet', 'cwipc_from_proxy_packet', 'CWIPC_FLAGS_BINARY', 'CwipcError',
     'CWIPC_LOG_LEVEL_NONE', 'CWIPC_LOG_LEVEL_ERROR', 'CWIPC_LOG_LEVEL_WARNING', 'CWIPC_LOG_LEVEL_TRACE', 'CWIPC_LOG_LEVEL_DEBUG',
     'cwipc_pointcloud_wrapper', 'cwipc_source_wrapper', 'cwipc_activesource_wrapper', 'cwipc_sink_wrapper', 'cwipc_metadata',
     'cwipc_point', 'cwipc_point_array', 'cwipc_point_numpy_dtype', 'cwipc_tileinfo_dict', 'cwipc_point_packetheader',
@@ -222,6 +222,8 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_comm_nranks': ([_c.c_void_p], _c.c_int),
     'cwipc_hip_comm_join': ([_c.c_void_p, cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
     'cwipc_hip_comm_submit': ([_c.c_void_p, cwipc_pointcloud_p, _c.c_int], cwipc_pointcloud_p),
+    'cwipc_hip_proxy_packet': ([cwipc_pointcloud_p, _c.c_void_p, _c.c_size_t, _c.c_uint32], _c.c_size_t),
+    'cwipc_hip_from_proxy_packet': ([_c.c_void_p, _c.c_size_t, _c.c_int, _c.POINTER(_c.c_char_p), _c.c_uint64], cwipc_pointcloud_p),
     'cwipc_hip_profile_enable': ([_c.c_int], None),
     'cwipc_hip_profile_reset': ([], None),
     'cwipc_hip_profile_count': ([], _c.c_int),
@@ -689,6 +691,39 @@ def cwipc_from_packet(packet: Union[bytes, bytearray]) -> cwipc_pointcloud_wrapp
     if rv:
         return cwipc_pointcloud_wrapper(rv)
     raise CwipcError("cwipc_from_packet: no pointcloud read, but no specific error returned from C library")
+
+
+CWIPC_POINT_PACKETHEADER_MAGIC_C = 0x20201016   # what the reference's proxy SERVER checks (include/cwipc_util/api.h:110); the Python constant above is what its SENDER writes
+
+
+def cwipc_proxy_packet(pc: cwipc_pointcloud_wrapper, magic: Optional[int] = None) -> bytes:
+    """The bytes the reference's sender puts on the wire for `pc` (python/cwipc/scripts/cwipc_toproxy.py:51-57): a 24-byte
+    cwipc_point_packetheader and the cwipc_point records.  magic: None = the C server's (0x20201016); the reference's Python
+    sender writes CWIPC_POINT_PACKETHEADER_MAGIC (0x20210208), which its own server refuses."""
+    dll = cwipc_util_dll_load()
+    need = dll.cwipc_hip_proxy_packet(pc.as_cwipc_p(), None, 0, 0)
+    if need == 0:
+        raise CwipcError("cwipc_proxy_packet: NULL pointcloud")
+    buf = bytearray(need)
+    c_buf = (ctypes.c_char * need).from_buffer(buf)
+    got = dll.cwipc_hip_proxy_packet(pc.as_cwipc_p(), ctypes.addressof(c_buf), need, 0 if magic is None else magic)
+    del c_buf
+    if got != need:
+        raise CwipcError("cwipc_proxy_packet: could not build the packet")
+    return bytes(buf)
+
+
+def cwipc_from_proxy_packet(packet: Union[bytes, bytearray], accept_python_magic: bool = False) -> cwipc_pointcloud_wrapper:
+    """What the reference's proxy server does with one packet (src/cwipc_proxy.cpp:179-216): the cloud, with the header's
+    timestamp (the 8 bytes the server sends back) and cellsize."""
+    n = len(packet)
+    c_packet = (ctypes.c_char * n).from_buffer_copy(packet)
+    errorString = ctypes.c_char_p()
+    rv = cwipc_util_dll_load().cwipc_hip_from_proxy_packet(ctypes.addressof(c_packet), n, 1 if accept_python_magic else 0, ctypes.byref(errorString), CWIPC_API_VERSION)
+    _raise_or_warn(errorString, None)
+    if rv:
+        return cwipc_pointcloud_wrapper(rv)
+    raise CwipcError("cwipc_from_proxy_packet: no pointcloud read, but no specific error returned from C library")
 
 
 def cwipc_read_debugdump(filename: str) -> cwipc_pointcloud_wrapper:

@@ -66,7 +66,7 @@ struct cwipc_point {
     uint8_t tile;
 };
 
-/* reference api.h:100-110 -- proxy wire header (transport is out of scope; kept for layout completeness) */
+/* reference api.h:100-110 -- proxy wire header (packet codec: cwipc_hip_proxy_packet / cwipc_hip_from_proxy_packet in cwipc_util_amd/hip_ext.h; the TCP transport is out of scope) */
 struct cwipc_point_packetheader {
     uint32_t magic;
     uint32_t dataCount;

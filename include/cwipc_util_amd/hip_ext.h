@@ -91,6 +91,16 @@ _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_comm_submit(cwipc_hip_comm *comm,
 _CWIPC_UTIL_EXPORT int cwipc_hip_exchange_plan(int rank, int nranks, const uint32_t *metas, int loopback, uint64_t *summary,
                                                uint64_t *sends, uint64_t *recvs, int cap);
 
+/* ---- the proxy's wire format as a packet codec (reference src/cwipc_proxy.cpp:179-216, include/cwipc_util/api.h:100-110) ----
+ * A packet = the 24-byte cwipc_point_packetheader + dataCount bytes of cwipc_point records; the receiver's answer is the 8 bytes of
+ * the timestamp.  No sockets here: the application moves the bytes.
+ * cwipc_hip_proxy_packet: writes the packet of `pc` (magic 0 = CWIPC_POINT_PACKETHEADER_MAGIC); packet NULL: returns the size it
+ * takes; returns the bytes written, 0 on error.  cwipc_hip_from_proxy_packet: the cloud of a packet (timestamp and cellsize from
+ * the header); the C magic is always accepted, the reference's Python sender's (0x20210208, python/cwipc/util.py:346 -- the two
+ * disagree upstream) only when accept_python_magic is set. */
+_CWIPC_UTIL_EXPORT size_t cwipc_hip_proxy_packet(cwipc_pointcloud *pc, uint8_t *packet, size_t size, uint32_t magic);
+_CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_from_proxy_packet(const uint8_t *packet, size_t size, int accept_python_magic, char **errorMessage, uint64_t apiVersion);
+
 /* ---- filters whose reference implementation is Python-side ---- */
 /* ColorizeFilter._mapcolor (reference python/cwipc/filters/colorize.py:100-119): lut = 256x3 doubles, valid = 256 flags. */
 _CWIPC_UTIL_EXPORT cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double weight, const double *lut, const uint8_t *valid);

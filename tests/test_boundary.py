@@ -400,3 +400,34 @@ def test_pcl_aware_caller_sees_an_empty_shared_ptr(cwipc, tmp_path):
                     "-o", exe, "-L" + libdir, "-lcwipc_util", "-Wl,-rpath," + libdir], check=True)
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
+
+
+def test_proxy_wire_format(cwipc):
+    """the proxy's packet (reference src/cwipc_proxy.cpp:179-216, include/cwipc_util/api.h:100-110) as a
+    codec.  Pinned by the reference's own sender, which builds the header with struct.pack("<iiqfi", magic, len(data),
+    timestamp, cellsize, 0) (python/cwipc/scripts/cwipc_toproxy.py:55), and by the server's checks."""
+    pc, pts = _build_pointcloud(cwipc)
+    pc._set_cellsize(0.125)
+    data = pc.get_bytes()
+    ts = pc.timestamp()
+    # what the codec writes is what the reference's sender would write (with the magic the reference's SERVER accepts)
+    packet = cwipc.cwipc_proxy_packet(pc)
+    assert packet == struct.pack("<iiqfi", 0x20201016, len(data), ts, 0.125, 0) + bytes(data) and len(packet) == 24 + 2 * 16
+    # ... and the server's side of it: cwipc_from_points(points, dataCount, dataCount / 16, timestamp), then the cellsize
+    back = cwipc.cwipc_from_proxy_packet(packet)
+    assert back.count() == 2 and back.timestamp() == ts and back.cellsize() == 0.125 and bytes(back.get_bytes()) == bytes(data)
+    # the magic the two halves of the reference disagree on: the Python sender's (util.py:346) is refused as the C server
+    # refuses it ("invalid magic number in packet header", cwipc_proxy.cpp:188) unless the caller says otherwise
+    assert cwipc.CWIPC_POINT_PACKETHEADER_MAGIC == 0x20210208 and cwipc.CWIPC_POINT_PACKETHEADER_MAGIC_C == 0x20201016
+    py_packet = struct.pack("<iiqfi", cwipc.CWIPC_POINT_PACKETHEADER_MAGIC, len(data), ts, 0.125, 0) + bytes(data)
+    assert cwipc.cwipc_proxy_packet(pc, cwipc.CWIPC_POINT_PACKETHEADER_MAGIC) == py_packet
+    with pytest.raises(cwipc.CwipcError, match="invalid magic"):
+        cwipc.cwipc_from_proxy_packet(py_packet)
+    assert bytes(cwipc.cwipc_from_proxy_packet(py_packet, accept_python_magic=True).get_bytes()) == bytes(data)
+    # damaged packets fail loudly: a short header, a length that does not match dataCount, a payload that is no whole number of records
+    for bad in (packet[:10], packet[:-1], packet + b"x", struct.pack("<iiqfi", 0x20201016, 17, ts, 0.125, 0) + b"y" * 17):
+        with pytest.raises(cwipc.CwipcError):
+            cwipc.cwipc_from_proxy_packet(bad)
+    # an empty cloud travels as a bare header
+    empty = cwipc.cwipc_from_points(cwipc.cwipc_point_array(count=0), 5)
+    assert len(cwipc.cwipc_proxy_packet(empty)) == 24 and cwipc.cwipc_from_proxy_packet(cwipc.cwipc_proxy_packet(empty)).count() == 0
