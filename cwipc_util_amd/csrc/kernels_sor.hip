@@ -27,6 +27,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 
 namespace cwipc_amd {
 
@@ -295,13 +296,16 @@ constexpr int QB = 128;
 
 __global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
                                                           const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_count, int k,
-                                                          float *__restrict__ dist_out) {
+                                                          float *__restrict__ dist_out, float *__restrict__ scratch) {
     const Grid g = gm ? gm->g : gv;
     extern __shared__ float best_all[];
-    float *best = best_all + threadIdx.x;
+    // the lists live in LDS while (k + 1) x 128 floats fit there (k <= 319), in a slab of device memory per workgroup beyond
+    // (the reference takes any k: src/cwipc_filters.cpp:197-201); the workgroups walk over the query tiles
+    float *best = scratch ? scratch + (size_t)blockIdx.x * (size_t)(k + 1) * QB + threadIdx.x : best_all + threadIdx.x;
     const int want = k + 1;
-    size_t qi = (size_t)blockIdx.x * QB + threadIdx.x;
-    if (qi >= n) return;
+    for (size_t tile = blockIdx.x; tile * QB < n; tile += gridDim.x) {
+    size_t qi = tile * QB + threadIdx.x;
+    if (qi >= n) continue;
     const float4 q = sorted[qi];
     const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
     int have = 0;
@@ -362,6 +366,41 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_kernel(Grid gv, const GridMe
     double sum = 0.0;
     for (int j = 1; j < have; j++) sum += (double)sqrtf(best[j * QB]);
     dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
+    }
+}
+
+// Launch of the list variant: LDS for the lists as long as they fit (64 KB by default, up to 160 KB once the limit has been
+// raised), a slab of device memory per workgroup beyond.  `slab` receives the pool block to give back when the kernel is done.
+bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, size_t n, const uint32_t *cell_start, const uint32_t *cell_count, int k,
+                     float *dist_out, hipStream_t s, void **slab) {
+    *slab = nullptr;
+    const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
+    const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
+    if (shmem <= (size_t)160 * 1024 - 512) {
+        if (shmem > (size_t)64 * 1024) {
+            static std::mutex once;
+            static int raised_on = -1;
+            std::lock_guard<std::mutex> g(once);
+            if (raised_on != current_device()) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mean_dist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+                    return hip_failed(hipGetLastError(), "sor k-NN LDS limit", __FILE__, __LINE__);
+                raised_on = current_device();
+            }
+        }
+        CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, s, gv, gm, sorted, n, cell_start, cell_count, k, dist_out, (float *)nullptr);
+        return true;
+    }
+    unsigned blocks = std::min(qgrid, 1024u);
+    while (blocks > 64 && (size_t)blocks * shmem > ((size_t)4 << 30)) blocks /= 2;
+    if ((size_t)blocks * shmem > ((size_t)16 << 30)) {
+        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_remove_outliers", "kNeighbors is too large for the device memory the candidate lists would take");
+        return false;
+    }
+    float *scratch = (float *)pool_alloc((size_t)blocks * shmem);
+    if (!scratch) return false;
+    *slab = scratch;
+    CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(blocks), dim3(QB), 0, s, gv, gm, sorted, n, cell_start, cell_count, k, dist_out, scratch);
+    return true;
 }
 
 // The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
@@ -583,13 +622,14 @@ bool sor_dense_on_device(const DeviceSoA &src, int k, float *dev_dist, float *pa
         CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts, cursor,
                   sorted);
         const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
-        const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
         if (k + 1 <= 17) {
             CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
         } else if (k + 1 <= 33) {
             CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
         } else {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
+            void *slab = nullptr;
+            ok = launch_knn_list(unused, meta, sorted, n, starts, counts, k, dev_dist, c.stream, &slab);
+            c.free_later(slab);
         }
     }
     ok = hipGetLastError() == hipSuccess && ok;
@@ -614,10 +654,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         CW_HIP_TRY(hipMemsetAsync(dev_dist, 0, n * sizeof(float), c.stream));
         return c.sync();
     }
-    if (k > 120) {   // (k+1) * 128 lanes * 4 B of LDS per workgroup must stay below 64 KiB
-        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_remove_outliers", "kNeighbors > 120 is not supported by the HIP path");
-        return false;
-    }
+    // (any k, as the reference: lists in registers up to k = 32, in LDS up to k = 319, in device memory beyond: launch_knn_list)
 
     // 1. bounding box
     const unsigned nb = grid_for(n);
@@ -824,13 +861,14 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
                   cursor, sorted);
         // 4. the k-NN pass
         const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
-        const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
         if (k + 1 <= 17) {
             CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, counts, k, dev_dist);
         } else if (k + 1 <= 33) {
             CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, counts, k, dev_dist);
         } else {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, c.stream, g, (const GridMeta *)nullptr, sorted, n, starts, counts, k, dev_dist);
+            void *slab = nullptr;
+            ok = launch_knn_list(g, nullptr, sorted, n, starts, counts, k, dev_dist, c.stream, &slab);
+            c.free_later(slab);
         }
     }
     // no wait here: every caller has one further down (the compaction, a copy to the host), and the

@@ -938,6 +938,15 @@ def test_remove_outliers_synthetic(gpu, oracle, synth, npoints, k, mul):
     assert 0 < len(got) < len(pts)
 
 
+@pytest.mark.parametrize("npoints,k", [(20000, 100), (20000, 200), (6000, 400)])
+def test_remove_outliers_any_k(gpu, oracle, synth, npoints, k):
+    """The reference takes any kNeighbors (src/cwipc_filters.cpp:197-201 hands it to pcl unchecked); round 2 stopped at 120.
+    k = 100: lists in 64 KB of LDS; 200: in LDS above the default limit; 400: in a slab of device memory per workgroup."""
+    pts, cs = synth(npoints, 0.3)
+    got, exp = check_sor(gpu, oracle, pts, cs, k, 1.0)
+    assert 0 < len(got) < len(pts)
+
+
 def test_remove_outliers_random_cloud_with_outliers(gpu, oracle):
     rng = np.random.default_rng(9)
     n = 50000
