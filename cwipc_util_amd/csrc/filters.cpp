@@ -400,7 +400,7 @@ extern "C" cwipc_pointcloud *cwipc_downsample(cwipc_pointcloud *pc, float cellsi
     }
     int err = 0;
     std::shared_ptr<DeferredResult> pending;
-    auto dst = voxel_downsample(src, cellsize, leaf_split, &err, leaf_split ? &pending : nullptr);
+    auto dst = voxel_downsample(src, cellsize, leaf_split, &err, &pending);
     if (pending) {
         // a stream of frames: the result is handed out while its kernels run (it settles when somebody asks for its points)
         auto *rv = new cwipc_hip_pointcloud();

@@ -1833,6 +1833,8 @@ struct PendingVoxel : DeferredResult {
     bool known = false, ok = false, settled = false;
     uint32_t err = 0, m = 0;
     bool serial = false;                         // the pass ran the serial accumulate kernel (an ERR_CELL_RANGE is then that kernel's to answer for)
+    bool leaf_split = true;                      // octree pass; false: the plain grid, whose finalize kernels ran only if the index space fits (gspec)
+    GridSpec gspec{0, 0u, 0u, 0ull};
     bool partitioned = false;                    // the pass ran on a partitioned copy of the cloud ...
     uint32_t scatter = 0, steps_total = 0;       //   ... and this is how scattered the cloud was as it came (of how many wave steps)
     uint32_t leaves = 0;                         // leaf grids the pass used
@@ -1880,6 +1882,7 @@ struct Workspace {
     std::shared_ptr<struct PendingVoxel> pending;   // the pass still in flight on this workspace, if the call that started it has returned
     size_t hint_n = 0;                 // the kind of call ws.shrink was learned on
     float hint_cell = 0.f;
+    bool hint_split = true;
     bool head_clean[2] = {false, false};   // the block is known to be zero (the replay kernel of the pass before zeroed it)
     unsigned long long *leaf_keys = nullptr;
     unsigned long long *hash_keys = nullptr;
@@ -2109,6 +2112,11 @@ bool PendingVoxel::outcome_locked() {
     scatter = seen ? hw[C_SCATTER] : 0xffffffffu;
     leaves = seen ? hw[C_LEAVES] : 0u;
     ok = seen && err == 0u && m <= spec_cap;
+    if (ok && !leaf_split) {
+        // did the speculative passes run?  (the test they made on the device, on the same words)
+        const unsigned long long cells = (unsigned long long)hw[C_DIVB] * hw[C_DIVB + 1] * hw[C_DIVB + 2];
+        ok = cells <= gspec.cells_max && (cells + 31) / 32 <= gspec.words_cap;
+    }
     return ok;
 }
 
@@ -2116,7 +2124,10 @@ std::shared_ptr<DeviceSoA> PendingVoxel::settle() {
     std::lock_guard<std::recursive_mutex> g(lock);
     if (settled) return result;
     if (outcome_locked()) {
-        if (m == 0) {
+        if (m == 0 && !leaf_split) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "VoxelGrid filter produced empty pointcloud");   // reference src/cwipc_filters.cpp:58-62
+            result = nullptr;
+        } else if (m == 0) {
             result = soa_alloc(0);   // only points that do not count: no leaves, an empty cloud
         } else {
             spec_dst->npoints = m;   // the finalize kernel is filling (or has filled) the first m slots; the planes carry its `ready` event
@@ -2126,7 +2137,7 @@ std::shared_ptr<DeviceSoA> PendingVoxel::settle() {
         // not a pass that could be handed out early after all: once more, the waiting way (the dirty records of the
         // failed pass are cleaned by the next user of its workspace)
         int code = 0;
-        result = voxel_downsample(src, cellsize, true, &code, nullptr);
+        result = voxel_downsample(src, cellsize, leaf_split, &code, nullptr);
     }
     spec_dst.reset();
     src.reset();
@@ -2161,12 +2172,12 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         const std::shared_ptr<PendingVoxel> p = ws.pending;
         ws.pending.reset();
         if (p->outcome()) {
-            ws.last_m = p->m;
+            if (p->leaf_split) ws.last_m = p->m; else ws.last_m_grid = p->m;
             ws.note_leaves(p->leaves);
             // (a partitioned pass tells how scattered the cloud was as it came: in scan order again, no partition next time)
             if (p->partitioned && (size_t)p->scatter * 4 < p->steps_total) ws.incoherent = false;
         } else {
-            ws.last_m = 0;
+            if (p->leaf_split) ws.last_m = 0; else ws.last_m_grid = 0;
             ws.streak = 0;
             if (p->err & ERR_SERIAL_PATH) ws.no_serial = true;
             else if (p->serial && (p->err & ERR_CELL_RANGE)) ws.no_serial = true;
@@ -2204,7 +2215,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     // Clouds with few points per voxel fill the workgroup table (2048 voxels): the previous calls of this
     // thread tell (ws.shrink) how much smaller the workgroups have to be for it to hold; the extra
     // workgroups run one after the other on the same CUs.
-    if (ws.hint_cell != cellsize || n > 2 * ws.hint_n || 2 * n < ws.hint_n) {   // another kind of cloud: start over
+    if (ws.hint_cell != cellsize || ws.hint_split != leaf_split || n > 2 * ws.hint_n || 2 * n < ws.hint_n) {   // another kind of cloud or call: start over
         ws.shrink = 0;
         ws.calm = 0;
         ws.incoherent = false;
@@ -2213,6 +2224,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.streak = 0;
     }
     ws.hint_cell = cellsize;
+    ws.hint_split = leaf_split;
     ws.hint_n = n;
     size_t nwaves = ((size_t)cus * K1_WAVES) << ws.shrink;
     const size_t steps_total = (n + WAVE_STEP - 1) / WAVE_STEP;
@@ -2489,28 +2501,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                 spec_dst->mark_pending(c.stream);
             }
         }
-        // A stream of frames (the two passes before went through at the first attempt): the call returns here, with its
-        // three kernels in flight.  The host does not wait for the count any more, so the next call's accumulate kernel
-        // is queued while this pass's replay and finalize kernels still run (on the thread's other stream), and the
-        // 15 us that lay between two accumulate kernels (replay kernel + the host's return, next entry and launch) are gone.
-        static const bool defer_on = []() { const char *e = getenv("CWIPC_DEFER"); return !e || atoi(e) != 0; }();
-        if (deferred && defer_on && leaf_split && attempt == 0 && ok && spec_dst && ws.streak >= 2) {
-            auto p = std::make_shared<PendingVoxel>();
-            p->src = src_ptr;
-            p->spec_dst = spec_dst;
-            p->words = reinterpret_cast<volatile unsigned long long *>(ws.host_words);
-            p->stream = c.stream;
-            p->seq = seq;
-            p->spec_cap = spec_cap;
-            p->cellsize = cellsize;
-            p->serial = used_serial;
-            p->partitioned = partition;
-            p->steps_total = (uint32_t)steps_total;
-            src.note_reader(c.stream);   // the input's planes are not recycled before the accumulate kernel is done with them
-            ws.pending = p;
-            *deferred = p;
-            return nullptr;
-        }
         // Plain grid: the same, five small kernels instead of one (mark, block counts, block scan, emit, unmark), with
         // room for last call's count (+25 %) and the index bitmap as it stands; each of them checks on the device
         // that the pass succeeded and fits, and does nothing otherwise.
@@ -2532,6 +2522,30 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                 hipLaunchKernelGGL(grid_unmark_kernel, dim3(sgrid), dim3(256), 0, c.stream, W, 0u, gspec, ws.order, ws.gbits);
                 spec_dst->mark_pending(c.stream);
             }
+        }
+        // A stream of frames (the two passes before went through at the first attempt): the call returns here, with its
+        // kernels in flight (r3: the plain grid's seven too).  The host does not wait for the count any more, so the next call's accumulate kernel
+        // is queued while this pass's replay and finalize kernels still run (on the thread's other stream), and the
+        // 15 us that lay between two accumulate kernels (replay kernel + the host's return, next entry and launch) are gone.
+        static const bool defer_on = []() { const char *e = getenv("CWIPC_DEFER"); return !e || atoi(e) != 0; }();
+        if (deferred && defer_on && attempt == 0 && ok && spec_dst && (leaf_split || gspec.on) && ws.streak >= 2) {
+            auto p = std::make_shared<PendingVoxel>();
+            p->src = src_ptr;
+            p->spec_dst = spec_dst;
+            p->words = reinterpret_cast<volatile unsigned long long *>(ws.host_words);
+            p->stream = c.stream;
+            p->seq = seq;
+            p->spec_cap = spec_cap;
+            p->cellsize = cellsize;
+            p->serial = used_serial;
+            p->leaf_split = leaf_split;
+            p->gspec = gspec;
+            p->partitioned = partition;
+            p->steps_total = (uint32_t)steps_total;
+            src.note_reader(c.stream);   // the input's planes are not recycled before the accumulate kernel is done with them
+            ws.pending = p;
+            *deferred = p;
+            return nullptr;
         }
         // wait for the replay kernel's sequence number in pinned memory (a few hundred microseconds of
         // polling at most, then the ordinary stream wait, which also reports launch failures)
@@ -2793,7 +2807,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             }
             return soa_alloc(0);
         }
-        if (leaf_split) ws.streak = attempt == 0 ? ws.streak + 1 : 0;
+        ws.streak = attempt == 0 ? ws.streak + 1 : 0;
         ws.note_leaves(hw[C_LEAVES]);
         return dst;
     }

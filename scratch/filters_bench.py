@@ -22,10 +22,16 @@ def single(f, reps=20):
     for i in range(reps):
         sync(); t0 = time.perf_counter(); f(pcs[i % 4]); sync(); ts.append(time.perf_counter() - t0)
     return float(np.median(ts))
+def counted(f, reps=20):   # a caller that asks for the count right after every call (the reference's VoxelizeFilter statistics do)
+    ts = []
+    for i in range(reps + 5):
+        sync(); t0 = time.perf_counter(); f(pcs[i % 4]).count(); dt = time.perf_counter() - t0
+        if i >= 5: ts.append(dt)
+    return float(np.median(ts))
 for name, f in [('tilefilter(1)', lambda pc: cw.cwipc_tilefilter(pc, 1)), ('crop', lambda pc: cw.cwipc_crop(pc, [-0.1, 0.1, 0.0, 1.0, -1, 1])),
                 ('colormap', lambda pc: cw.cwipc_colormap(pc, 0xff000000, 0x01000000)), ('tilemap', lambda pc: cw.cwipc_tilemap(pc, list(range(256)))),
                 ('join(pc,pc)', lambda pc: cw.cwipc_join(pc, pc)), ('downsample(+0.01)', lambda pc: cw.cwipc_downsample(pc, 0.01)),
                 ('downsample(-0.01)', lambda pc: cw.cwipc_downsample(pc, -0.01))]:
-    a, b = stream(f), single(f)
-    res[name] = {'stream_us': round(a * 1e6, 1), 'single_us': round(b * 1e6, 1), 'stream_Gpoints_s': round(n / a / 1e9, 1)}
+    a, b, c = stream(f), single(f), counted(f)
+    res[name] = {'stream_us': round(a * 1e6, 1), 'single_us': round(b * 1e6, 1), 'call_then_count_us': round(c * 1e6, 1), 'stream_Gpoints_s': round(n / a / 1e9, 1)}
 print(json.dumps(res, indent=1))
