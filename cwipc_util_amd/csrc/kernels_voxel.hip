@@ -2426,6 +2426,13 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
+            {
+                // waves that take tiles: all twelve.  (Fewer, so that the range's tiles make full rounds -- 79 tiles are 8 rounds of
+                // 10 waves but 7 rounds of 12 with the last one half empty -- was measured: 12 waves 53.9 us, 11: 54.9, 10: 55.6,
+                // 9: 57.0 at 10 M points.  CWIPC_SERIAL_WAVES=n overrides.)
+                static const int waves_knob = []() { const char *e = getenv("CWIPC_SERIAL_WAVES"); return e ? atoi(e) : 0; }();
+                F.active_waves = waves_knob > 0 ? (uint32_t)waves_knob : (uint32_t)SK_WAVES;
+            }
 #ifdef CWIPC_DEBUG_KNOBS
             static const uint32_t serial_dbg = []() { const char *e = getenv("CWIPC_SERIAL_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
             if (serial_dbg) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_SERIAL_DBG is set: results are WRONG (timing experiments only)");
