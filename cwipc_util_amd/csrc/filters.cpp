@@ -149,10 +149,20 @@ extern "C" cwipc_pointcloud *cwipc_tilefilter(cwipc_pointcloud *pc, int tile) {
     // tile 0 keeps every point (reference :296): the result is the same cloud -- clouds are immutable, so it holds
     // the very same planes instead of a copy of them
     if (tile == 0) return wrap(src, pc->timestamp(), pc->cellsize());
+    // what is known about the cloud's tiles without looking at a point (DeviceSoA::tiles): a camera's own tile through its own
+    // filter -- the per-tile chain of the reference's registration tooling -- is the cloud itself; a tile that cannot occur is empty
+    if (src->npoints && src->only_tile((unsigned)tile)) return wrap(src, pc->timestamp(), pc->cellsize());
+    if (src->npoints && !src->may_have_tile((unsigned)tile)) {
+        auto none = soa_alloc(0);
+        if (none) none->set_one_tile((unsigned)tile);
+        return wrap(none, pc->timestamp(), pc->cellsize());
+    }
     k::Predicate p{};
     p.mode = 0;
     p.tile = tile;
-    return wrap(compact(*src, p, true), pc->timestamp(), pc->cellsize());
+    auto dst = compact(*src, p, true);
+    if (dst) dst->set_one_tile((unsigned)tile);   // (tile > 255 keeps nothing, reference :296; a set of "value 255 & ..." never matters for an empty cloud)
+    return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
 // reference python/cwipc/registration/util.py:98-112 (numpy boolean-mask selection)
@@ -164,7 +174,9 @@ extern "C" cwipc_pointcloud *cwipc_hip_tilefilter_masked(cwipc_pointcloud *pc, i
     k::Predicate p{};
     p.mode = 2;
     p.tile = mask & 0xff;
-    return wrap(compact(*src, p, true), pc->timestamp(), pc->cellsize());
+    auto dst = compact(*src, p, true);
+    if (dst) dst->set_tiles_from(*src);   // (a subset of the points: what could not occur still cannot)
+    return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
 // reference src/cwipc_filters.cpp:333-360
@@ -176,7 +188,9 @@ extern "C" cwipc_pointcloud *cwipc_crop(cwipc_pointcloud *pc, float bbox[6]) {
     k::Predicate p{};
     p.mode = 1;
     memcpy(p.bbox, bbox, 6 * sizeof(float));
-    return wrap(compact(*src, p, true), pc->timestamp(), pc->cellsize());
+    auto dst = compact(*src, p, true);
+    if (dst) dst->set_tiles_from(*src);   // (a subset of the points: what could not occur still cannot)
+    return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
 // reference src/cwipc_filters.cpp:308-331
@@ -196,6 +210,12 @@ extern "C" cwipc_pointcloud *cwipc_tilemap(cwipc_pointcloud *pc, uint8_t map[256
     ok = c.sync() && ok;
     if (!ok) return nullptr;
     inherit_first(*dst, *src);
+    {   // the tiles that may occur afterwards: the images of those that may occur now (of all 256 values if nothing is known)
+        dst->has_tiles = true;
+        for (int i = 0; i < 8; i++) dst->tiles[i] = 0;
+        for (unsigned t = 0; t < 256; t++)
+            if (src->may_have_tile(t)) dst->tiles[map[t] >> 5] |= 1u << (map[t] & 31u);
+    }
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
@@ -212,6 +232,12 @@ extern "C" cwipc_pointcloud *cwipc_colormap(cwipc_pointcloud *pc, uint32_t clear
     k::map_color_bits(*src, *dst, clearBits, setBits, c.stream);
     if (!c.sync()) return nullptr;
     inherit_first(*dst, *src);
+    if (src->has_tiles) {   // the tile is bits 24-31 of the word the masks work on (:377-378)
+        dst->has_tiles = true;
+        for (int i = 0; i < 8; i++) dst->tiles[i] = 0;
+        for (unsigned t = 0; t < 256; t++)
+            if (src->may_have_tile(t)) { const unsigned u = ((t & ~(clearBits >> 24)) | (setBits >> 24)) & 255u; dst->tiles[u >> 5] |= 1u << (u & 31u); }
+    }
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
@@ -270,6 +296,8 @@ extern "C" int cwipc_hip_tiles_used(cwipc_pointcloud *pc, uint8_t *used256) {
         used256[t] = (c.host_words[t >> 5] >> (t & 31)) & 1u;
         count += used256[t];
     }
+    src->has_tiles = true;   // (a census: remembered on the cloud)
+    for (int w = 0; w < 8; w++) src->tiles[w] = c.host_words[w];
     return count;
 }
 
@@ -316,6 +344,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double wei
     pool_free(dev_table);
     if (!ok) return nullptr;
     inherit_first(*dst, *src);
+    dst->set_tiles_from(*src);   // (colours change, tiles do not)
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
 
@@ -367,6 +396,16 @@ extern "C" cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int np
     }
     dst->mark_pending(c.stream);
     for (int i = 0; i < npc; i++) if (src[i]->npoints) src[i]->note_reader(c.stream);
+    {   // the tiles that may occur: the union over the parts that hold points (unknown as soon as one of them is)
+        bool known = true;
+        uint32_t u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < npc; i++) {
+            if (!src[i]->npoints) continue;
+            known = known && src[i]->has_tiles;
+            for (int w = 0; w < 8; w++) u[w] |= src[i]->tiles[w];
+        }
+        if (known) { dst->has_tiles = true; for (int w = 0; w < 8; w++) dst->tiles[w] = u[w]; }
+    }
     return wrap(dst, ts, cellsize);
 }
 

@@ -149,6 +149,21 @@ struct DeviceSoA {
     // anchored there); fetched from the device on demand otherwise.
     mutable bool has_first = false;
     mutable float first[3] = {0, 0, 0};
+    // Which tile values MAY occur in the cloud (bit t of 256), when a producer knows: a tilemap with one target value, a tile
+    // filter's result, the synthetic source, a census (cwipc_hip_tiles_used); filters that keep the tile words hand it on,
+    // a join takes the union.  A one-element set on a cloud with points says that EVERY point has that tile: cwipc_tilefilter
+    // for it hands the planes on without looking at a point (a camera's tile is filtered by its own mask in the per-tile chain
+    // of the reference, python/cwipc/registration/util.py:170-182), and a filter for a value outside the set is empty.
+    mutable bool has_tiles = false;
+    mutable uint32_t tiles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void set_tiles_from(const DeviceSoA &o) const { has_tiles = o.has_tiles; for (int i = 0; i < 8; i++) tiles[i] = o.tiles[i]; }
+    void set_one_tile(unsigned t) const { has_tiles = true; for (int i = 0; i < 8; i++) tiles[i] = 0; tiles[(t & 255u) >> 5] = 1u << (t & 31u); }
+    bool may_have_tile(unsigned t) const { return !has_tiles || t > 255u || ((tiles[t >> 5] >> (t & 31u)) & 1u) != 0u; }
+    bool only_tile(unsigned t) const {
+        if (!has_tiles || t > 255u) return false;
+        for (int i = 0; i < 8; i++) if (tiles[i] != (i == (int)(t >> 5) ? 1u << (t & 31u) : 0u)) return false;
+        return true;
+    }
     // Set (before the cloud is published) when the producing call returned with its last kernel
     // still running: every consumer orders its stream after this event; never changed afterwards.
     hipEvent_t ready = nullptr;

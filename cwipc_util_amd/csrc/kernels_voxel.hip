@@ -1970,6 +1970,7 @@ struct WorkspaceLease {
 };
 thread_local WorkspaceLease t_ws;
 thread_local int t_ws_next = 0;
+thread_local int t_ws_idle = 0;   // calls in a row that found both of the thread's streams idle while it holds a second workspace
 
 // For the duration of a call: the thread's current stream is the one of the workspace in use.
 struct StreamOfWorkspace {
@@ -2162,6 +2163,18 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         which = 0;
         if (t_ws.ws[0] && c.stream && hipStreamQuery(c.stream) == hipErrorNotReady) which = 1;
         (void)hipGetLastError();   // (hipErrorNotReady is an answer, not a failure)
+    } else if (c.stream && c.stream_alt && !t_ws.ws[1]->pending) {
+        // ... and goes again when it has not been needed for a while: sixteen calls in a row that found both streams idle (a
+        // thread that has stopped calling back to back: 0.3 GB of leaf grids it no longer needs)
+        const bool idle = hipStreamQuery(c.stream) == hipSuccess && hipStreamQuery(c.stream_alt) == hipSuccess;
+        (void)hipGetLastError();
+        t_ws_idle = idle ? t_ws_idle + 1 : 0;
+        if (t_ws_idle >= 16) {
+            delete t_ws.ws[1];
+            t_ws.ws[1] = nullptr;
+            t_ws_idle = 0;
+            which = 0;
+        }
     }
     t_ws_next = which ^ 1;
     Workspace &ws = t_ws.get(which);

@@ -79,6 +79,7 @@ std::shared_ptr<DeviceSoA> soa_with_new_xyz(const std::shared_ptr<DeviceSoA> &sr
     soa->stride = src->stride;
     soa->device = src->device;
     soa->rgbt_block = src->rgbt_block;
+    soa->set_tiles_from(*src);   // (the very same tile words)
     void *xyz = pool_alloc(soa->stride * 12);
     if (!xyz) return nullptr;
     soa->xyz_block = std::make_shared<PlaneBlock>(xyz);

@@ -39,7 +39,7 @@ __all__ = [
     'cwipc_downsample', 'cwipc_remove_outliers', 'cwipc_tilefilter', 'cwipc_tilemap', 'cwipc_colormap',
     'cwipc_join', 'cwipc_join_multi', 'cwipc_crop',
     # MI355X extensions (no reference counterpart)
-    'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked',
+    'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked', 'cwipc_hip_device_planes',
     'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_from_device_slots', 'cwipc_hip_copy_device_aos',
     'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_hip_simulatecams', 'cwipc_hip_comm', 'cwipc_hip_comm_unique_id',
 ]
@@ -862,6 +862,17 @@ def cwipc_hip_upload(pc: cwipc_pointcloud_wrapper, drop_host_copy: bool = False)
         raise CwipcError("cwipc_hip_upload failed: " + dll.cwipc_hip_last_error().decode('utf8'))
     if drop_host_copy:
         dll.cwipc_hip_drop_host_copy(pc.as_cwipc_p())
+
+
+def cwipc_hip_device_planes(pc: cwipc_pointcloud_wrapper) -> Tuple[int, int, int, int, int]:
+    """Device addresses of the cloud's planes (x, y, z: float32[n]; rgbt: uint32[n] = r | g << 8 | b << 16 | tile << 24) and n.
+    Uploads the cloud if it is not resident.  For zero-copy hand-over to other device code (and for tests that ask whether
+    two clouds share their planes)."""
+    x, y, z, w = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    n = ctypes.c_size_t(0)
+    if cwipc_util_dll_load().cwipc_hip_device_planes(pc.as_cwipc_p(), ctypes.byref(x), ctypes.byref(y), ctypes.byref(z), ctypes.byref(w), ctypes.byref(n)) != 0:
+        raise CwipcError("cwipc_hip_device_planes failed")
+    return (x.value or 0, y.value or 0, z.value or 0, w.value or 0, n.value)
 
 
 def cwipc_hip_colorize(pc: cwipc_pointcloud_wrapper, weight: float, lut: numpy.ndarray, valid: numpy.ndarray) -> cwipc_pointcloud_wrapper:

@@ -307,6 +307,42 @@ def test_tiles_used(gpu, oracle, synth):
     assert gpu.get_tiles_used(make_cloud(gpu, pts[:0], cs)) == []
 
 
+def test_tile_sets_known_without_looking(gpu, oracle, synth):
+    """What a device cloud knows about its tiles (a tilemap with one target, a tile filter's result, a census, the union in a
+    join) lets cwipc_tilefilter answer without a kernel where the answer is "all" or "none" -- a camera's tile through its own
+    mask is the first step of the reference's per-tile chain (python/cwipc/registration/util.py:170-182).  Results are the
+    oracle's either way; the planes are shared where nothing is copied."""
+    pts, cs = synth(100000)
+    pc = make_cloud(gpu, pts, cs, 5)
+    def planes(c):
+        return gpu.cwipc_hip_device_planes(c)[:4]
+    cam = gpu.cwipc_tilemap(pc, bytes([8]) * 256)                       # every point -> tile 8: the set is {8}
+    exp_cam = oracle.tilemap(pts, np.full(256, 8, dtype=np.uint8))
+    own = gpu.cwipc_tilefilter(cam, 8)
+    assert same(own.get_numpy_array(), oracle.tilefilter(exp_cam, 8)) and planes(own) == planes(cam)
+    other = gpu.cwipc_tilefilter(cam, 4)
+    assert other.count() == 0 and other.timestamp() == 5 and other.cellsize() == cam.cellsize()
+    # through filters that keep the tile words, and a colormap that rewrites them
+    moved = gpu.cwipc_transform(cam, np.eye(4))
+    assert planes(gpu.cwipc_tilefilter(moved, 8)) == planes(moved)
+    recol = gpu.cwipc_colormap(cam, 0xff000000, 0x05000000)             # tile byte cleared, set to 5
+    assert gpu.cwipc_tilefilter(recol, 8).count() == 0 and gpu.cwipc_tilefilter(recol, 5).count() == len(pts)
+    assert same(gpu.cwipc_tilefilter(recol, 5).get_numpy_array(), oracle.tilefilter(oracle.colormap(exp_cam, 0xff000000, 0x05000000), 5))
+    # a join knows the union: both filters really filter, a third value is empty
+    cam2 = gpu.cwipc_tilemap(pc, bytes([16]) * 256)
+    both = gpu.cwipc_join(cam, cam2)
+    exp_both = oracle.join(exp_cam, oracle.tilemap(pts, np.full(256, 16, dtype=np.uint8)))
+    for t in (8, 16, 1):
+        assert same(gpu.cwipc_tilefilter(both, t).get_numpy_array(), oracle.tilefilter(exp_both, t)), t
+    # an uploaded cloud knows nothing until somebody takes a census; afterwards the one-tile half is handed on as it is
+    t1 = gpu.cwipc_tilefilter(pc, 1)                                     # (a real filter; its result's set is {1})
+    assert same(t1.get_numpy_array(), oracle.tilefilter(pts, 1)) and planes(gpu.cwipc_tilefilter(t1, 1)) == planes(t1)
+    up = make_cloud(gpu, oracle.tilefilter(pts, 2), cs, 6)
+    assert gpu.get_tiles_used(up) == [2]
+    again = gpu.cwipc_tilefilter(up, 2)
+    assert planes(again) == planes(up) and gpu.cwipc_tilefilter(up, 1).count() == 0
+
+
 # ---------------------------------------------------------------------------
 # voxel downsample
 # ---------------------------------------------------------------------------
