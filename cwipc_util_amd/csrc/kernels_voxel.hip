@@ -2622,6 +2622,14 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
                     snprintf(buf, sizeof(buf), "debug: %u workgroups: last start %.2f us after the first; records updated between %.2f and %.2f us; all waves done by %.2f; a workgroup lives %.2f to %.2f us",
                              fast_blocks, (double)(s_max - t0) * 0.01, (double)(e_min - t0) * 0.01, (double)(e_max - t0) * 0.01, (double)(a_max - t0) * 0.01, (double)d_min * 0.01, (double)d_max * 0.01);
                     cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", buf);
+                    if (const char *path = getenv("CWIPC_FAST_STAMPS_FILE")) {   // every workgroup's row, for a look at the spread
+                        if (FILE *f = fopen(path, "w")) {
+                            fprintf(f, "# workgroup start stream_done(thread 0's wave) all_waves_done end   (us since the first start)\n");
+                            for (uint32_t b = 0; b < fast_blocks; b++)
+                                fprintf(f, "%u %.2f %.2f %.2f %.2f\n", b, (double)(wt[b][0] - t0) * 0.01, (double)(wt[b][1] - t0) * 0.01, (double)(wt[b][2] - t0) * 0.01, (double)(wt[b][3] - t0) * 0.01);
+                            fclose(f);
+                        }
+                    }
                 }
                 unsigned long long wd[K1_WAVES];
                 if (hipMemcpyFromSymbol(wd, HIP_SYMBOL(g_fast_wave_done), sizeof(wd)) == hipSuccess) {
