@@ -1157,7 +1157,6 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
 }
 
 #include "voxel_k1_fast.inc"
-#include "voxel_k1_serial.inc"
 #include "voxel_partition.inc"
 
 // ---------------------------------------------------------------------------
@@ -1832,7 +1831,6 @@ struct PendingVoxel : DeferredResult {
     float cellsize = 0;
     bool known = false, ok = false, settled = false;
     uint32_t err = 0, m = 0;
-    bool serial = false;                         // the pass ran the serial accumulate kernel (an ERR_CELL_RANGE is then that kernel's to answer for)
     bool leaf_split = true;                      // octree pass; false: the plain grid, whose finalize kernels ran only if the index space fits (gspec)
     GridSpec gspec{0, 0u, 0u, 0ull};
     bool partitioned = false;                    // the pass ran on a partitioned copy of the cloud ...
@@ -1862,7 +1860,6 @@ struct Workspace {
     int calm = 0;                      // calls in a row whose tables stayed less than a third full
     bool incoherent = false;           // smaller workgroups did not stop the overflows: stay with full-size ones
     bool no_fast = false;              // the fast accumulate kernel gave this kind of cloud back (ERR_FAST_PATH): use the general one
-    bool no_serial = false;            // the serial accumulate kernel gave this kind of cloud back (ERR_SERIAL_PATH): use the fast one
     int streak = 0;                    // octree passes of this kind in a row that went through without a retry
     int roomy = 0;                     // passes in a row that used at most a quarter of the leaf grids
     uint32_t shrink_to = 0;            // != 0: give the grids back and start again with this many (at the next call, when nothing is in flight)
@@ -1998,8 +1995,6 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         const int lds_fast = (int)sizeof(FastTable);
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
-        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_serial_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SerialShared)));
-        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_serial_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SerialShared)));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&partition_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         ws.device = dev;
     }
@@ -2192,9 +2187,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         } else {
             if (p->leaf_split) ws.last_m = 0; else ws.last_m_grid = 0;
             ws.streak = 0;
-            if (p->err & ERR_SERIAL_PATH) ws.no_serial = true;
-            else if (p->serial && (p->err & ERR_CELL_RANGE)) ws.no_serial = true;
-            else if (p->err & (ERR_FAST_PATH | ERR_CELL_RANGE)) ws.no_fast = true;
+            if (p->err & (ERR_FAST_PATH | ERR_CELL_RANGE)) ws.no_fast = true;
             VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
             CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
             if (!c.sync()) { hip_failed(hipGetLastError(), "voxel workspace clean-up", __FILE__, __LINE__); return nullptr; }
@@ -2233,7 +2226,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.calm = 0;
         ws.incoherent = false;
         ws.no_fast = false;
-        ws.no_serial = false;
         ws.streak = 0;
     }
     ws.hint_cell = cellsize;
@@ -2352,7 +2344,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     if (ws.shrink_to) ws.roomy = 0;
     ws.shrink_to = 0;
     int mode = leaf_split ? 1 : 0;
-    bool used_fast = false, used_serial = false;
+    bool used_fast = false;
     for (int attempt = 0; attempt < 10; attempt++) {
         if (!ensure_workspace(ws, n, leaf_cap, (uint32_t)nwaves, c.stream)) return nullptr;
         P.leaf_mask = 4 * ws.leaf_cap - 1;
@@ -2421,44 +2413,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             Wk.bboxes = ws.bboxes + (size_t)ws.bbox_cap * 6;   // the boxes of the moved points: nobody reads them
         }
         used_fast = fast;
-        // ... and the serial variant (voxel_k1_serial.inc) takes them first: the same sums from a third of the instructions
-        // (while it is the slower of the two it runs only when asked for: CWIPC_VOXEL_SERIAL=1)
-        static const bool serial_off = []() { const char *e = getenv("CWIPC_VOXEL_SERIAL"); return !e || atoi(e) == 0; }();
-        const bool serial = fast && !ws.no_serial && !serial_off;
-        used_serial = serial;
         uint32_t fast_blocks = 0, fast_per_wg = 0;
-        if (serial) {
-            FastParams F;
-            memset(&F, 0, sizeof(F));
-            // the workgroups' ranges: the cloud's tiles dealt evenly over the CUs the grid may use
-            const size_t tiles_total = (n + SK_TILE - 1) / SK_TILE;
-            const size_t wg_tiles = std::min<size_t>(std::max<size_t>((tiles_total + (size_t)cus - 1) / (size_t)cus, 1), SK_MAX_TILES);
-            fast_blocks = (uint32_t)((tiles_total + wg_tiles - 1) / wg_tiles);
-            fast_per_wg = (uint32_t)(wg_tiles * SK_TILE);
-            F.n = K.n; F.per_wg = fast_per_wg; F.inv_leaf = K.inv_leaf;
-            F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
-            F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
-            F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
-            {
-                // waves that take tiles: all twelve.  (Fewer, so that the range's tiles make full rounds -- 79 tiles are 8 rounds of
-                // 10 waves but 7 rounds of 12 with the last one half empty -- was measured: 12 waves 53.9 us, 11: 54.9, 10: 55.6,
-                // 9: 57.0 at 10 M points.  CWIPC_SERIAL_WAVES=n overrides.)
-                static const int waves_knob = []() { const char *e = getenv("CWIPC_SERIAL_WAVES"); return e ? atoi(e) : 0; }();
-                F.active_waves = waves_knob > 0 ? (uint32_t)waves_knob : (uint32_t)SK_WAVES;
-            }
-#ifdef CWIPC_DEBUG_KNOBS
-            static const uint32_t serial_dbg = []() { const char *e = getenv("CWIPC_SERIAL_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
-            if (serial_dbg) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_SERIAL_DBG is set: results are WRONG (timing experiments only)");
-            F.dbg = serial_dbg;
-#endif
-            if (mode == 0) {
-                CW_LAUNCH("voxel_accumulate", voxel_accumulate_serial_kernel<0>, dim3(fast_blocks), dim3(SK_THREADS), sizeof(SerialShared), c.stream, F, src.x(),
-                          src.y(), src.z(), src.rgbt(), W);
-            } else {
-                CW_LAUNCH("voxel_accumulate", voxel_accumulate_serial_kernel<1>, dim3(fast_blocks), dim3(SK_THREADS), sizeof(SerialShared), c.stream, F, src.x(),
-                          src.y(), src.z(), src.rgbt(), W);
-            }
-        } else if (fast) {
+        if (fast) {
             FastParams F;
             memset(&F, 0, sizeof(F));
             // The workgroups' ranges: the cloud's steps dealt evenly over the CUs the grid may use (a workgroup's waves share its
@@ -2557,7 +2513,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             p->seq = seq;
             p->spec_cap = spec_cap;
             p->cellsize = cellsize;
-            p->serial = used_serial;
             p->leaf_split = leaf_split;
             p->gspec = gspec;
             p->partitioned = partition;
@@ -2792,12 +2747,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         if (error_code) *error_code = (int)err;
         if (!ok) { hip_failed(hipGetLastError(), "voxel emit", __FILE__, __LINE__); return nullptr; }
 
-        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES | ERR_LIST_FULL | ERR_FAST_PATH | ERR_SERIAL_PATH | (used_fast ? ERR_CELL_RANGE : 0u);
-        if (used_serial && (err & (ERR_SERIAL_PATH | ERR_CELL_RANGE)) && !(err & ~retryable)) {
-            // not a cloud for the serial variant: the touched records were cleaned above; the fast variant is next
-            ws.no_serial = true;
-            continue;
-        }
+        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES | ERR_LIST_FULL | ERR_FAST_PATH | (used_fast ? ERR_CELL_RANGE : 0u);
         if (used_fast && (err & (ERR_FAST_PATH | ERR_CELL_RANGE)) && !(err & ~retryable)) {
             // not a cloud for the fast variant (its table, its key or its slabs): the touched records were cleaned above
             ws.no_fast = true;
