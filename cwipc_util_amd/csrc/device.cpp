@@ -251,6 +251,7 @@ bool ThreadCtx::ensure() {
             stream_alt = nullptr;
         }
         if (dev_words) { (void)hipFree(dev_words); dev_words = nullptr; }
+        if (tickets) { (void)hipFree(tickets); tickets = nullptr; }
     }
     device = dev;
     stream = retired_stream_take(dev);
@@ -259,6 +260,8 @@ bool ThreadCtx::ensure() {
     if (!stream_alt) CW_HIP_TRY(hipStreamCreateWithFlags(&stream_alt, hipStreamNonBlocking));
     if (!host_words) CW_HIP_TRY(hipHostMalloc((void **)&host_words, 64 * sizeof(uint32_t), hipHostMallocDefault));
     CW_HIP_TRY(hipMalloc(&dev_words, 64 * sizeof(uint32_t)));
+    CW_HIP_TRY(hipMalloc((void **)&tickets, 16 * sizeof(uint32_t)));
+    CW_HIP_TRY(hipMemsetAsync(tickets, 0, 16 * sizeof(uint32_t), stream));
     return true;
 }
 
@@ -321,6 +324,7 @@ ThreadCtx::~ThreadCtx() {
     if (pinned) (void)hipHostFree(pinned);
     if (host_words) (void)hipHostFree(host_words);
     if (dev_words) (void)hipFree(dev_words);
+    if (tickets) (void)hipFree(tickets);
     if (scratch) (void)hipFree(scratch);
     for (void *p : deferred) pool_free(p);
 }

@@ -84,6 +84,7 @@ struct ThreadCtx {
     size_t pinned_bytes = 0;
     uint32_t *host_words = nullptr;   // 64 pinned 32-bit words for small read-backs
     void *dev_words = nullptr;        // 64 device words
+    uint32_t *tickets = nullptr;      // 16 device words, zero between kernels: "last workgroup done" counters (each kernel that uses one sets it back)
     void *scratch = nullptr;          // device scratch of this thread's calls (block counts of a compaction): work on one
     size_t scratch_bytes = 0;         //   stream is ordered, so the next call may overwrite it while nobody else can
     uint32_t tag = 0;                 // sequence number of the last value a kernel published into host_words
@@ -327,6 +328,10 @@ struct Predicate {
 // Pass 1: per-block keep counts into block_counts[nblocks]; returns nblocks through the argument.
 size_t compact_blocks(size_t n);
 void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, hipStream_t s);
+// count and scan in one launch (the last workgroup to finish scans the block counts): for clouds of up to a million points,
+// where a launch costs the host more than the kernel costs the device; `ticket`: a zeroed device word, left zeroed
+bool compact_count_scan(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, uint32_t *ticket, unsigned long long *total_host, uint32_t tag,
+                        hipStream_t s);
 // Exclusive scan of block_counts in place; total written to *total_dev.
 void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *total_host, uint32_t tag, hipStream_t s);
 // Pass 2: scatter kept points to dst in input order.

@@ -105,9 +105,14 @@ void soa_to_aos(const DeviceSoA &src, cwipc_point *aos, size_t n, hipStream_t s)
 // from a wave64 ballot/popcount prefix -- so output order == input order.
 static constexpr int ITEMS = 4;                         // points per lane and step (one dwordx4 per plane)
 static constexpr int STEPS = 4;                         // steps per workgroup
-static constexpr int TILE = BLOCK * ITEMS * STEPS;      // 4096 points per workgroup
+static constexpr int TILE = BLOCK * ITEMS * STEPS;      // 4096 points per workgroup ...
+// ... and 1024 for clouds of up to 256 k points (round 3): a camera tile of 36 k points is nine workgroups of 4096, on nine of 256
+// compute units, each walking through its four steps (8.5 us for the scatter kernel alone)
+static constexpr size_t SMALL_CLOUD = 262144;
+static constexpr int SMALL_STEPS = 1;
+static constexpr int SMALL_TILE = BLOCK * ITEMS * SMALL_STEPS;
 
-size_t compact_blocks(size_t n) { return (n + TILE - 1) / TILE; }
+size_t compact_blocks(size_t n) { return n <= SMALL_CLOUD ? (n + SMALL_TILE - 1) / SMALL_TILE : (n + TILE - 1) / TILE; }
 
 struct PredArgs {
     int mode;
@@ -161,16 +166,17 @@ __device__ __forceinline__ unsigned lane_mask(const PredArgs &p, const float *__
     return m;
 }
 
+template <int S>
 __global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
                                                              uint32_t *__restrict__ block_counts) {
     __shared__ uint32_t wave_sum[WAVES];
-    size_t tile0 = (size_t)blockIdx.x * TILE;
+    size_t tile0 = (size_t)blockIdx.x * (BLOCK * ITEMS * S);
     uint32_t cnt = 0;
     float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
     uint4 vw;
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
+    for (int s = 0; s < S; s++) {
         size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
         unsigned m = (p.mode == 1) ? lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
                                    : lane_mask<false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
@@ -186,18 +192,17 @@ __global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const 
     }
 }
 
-// Exclusive scan of up to millions of block counts by ONE workgroup of 1024 lanes
-// (the count array is tiny: N/4096 entries).
-// The total goes to a pinned host word with `tag` in its upper half (one 64-bit store, no fence): the
-// host polls for the tag instead of waiting for the stream.
-__global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict__ counts, size_t nblocks, unsigned long long *__restrict__ total,
-                                                            uint32_t tag) {
-    __shared__ uint32_t wave_tot[16];
+// The exclusive scan of the block counts by the workgroup that runs it (NT lanes): counts[i] <- sum of those before, counts[nblocks]
+// <- the total, which also goes to a pinned host word with `tag` in its upper half (one 64-bit store, no fence: the host polls for
+// the tag instead of waiting for the stream).
+template <int NT>
+__device__ __forceinline__ void scan_block_counts(uint32_t *__restrict__ counts, size_t nblocks, unsigned long long *__restrict__ total, uint32_t tag) {
+    __shared__ uint32_t wave_tot[NT / 64];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (size_t base = 0; base < nblocks; base += 1024) {
+    for (size_t base = 0; base < nblocks; base += NT) {
         size_t i = base + threadIdx.x;
         uint32_t v = i < nblocks ? counts[i] : 0;
         uint32_t inc = v;
@@ -212,7 +217,7 @@ __global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict
         uint32_t c = carry;
         if (i < nblocks) counts[i] = c + wave_base + inc - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c + wave_base + inc;
+        if (threadIdx.x == NT - 1) carry = c + wave_base + inc;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -221,25 +226,73 @@ __global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict
     }
 }
 
+// Count and scan in one launch: every workgroup leaves its count and takes a ticket; the one that takes the last ticket has
+// every count in front of it (release / acquire at device scope around the ticket) and scans them.  For small clouds, whose
+// kernels cost the device less than their launches cost the host (a camera tile through the outlier filter: sixteen launches).
+template <int S>
+__global__ void __launch_bounds__(BLOCK) compact_count_scan_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
+                                                                  const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
+                                                                  uint32_t *__restrict__ block_counts, uint32_t *__restrict__ ticket,
+                                                                  unsigned long long *__restrict__ total, uint32_t tag) {
+    __shared__ uint32_t wave_sum[WAVES];
+    __shared__ uint32_t is_last;
+    size_t tile0 = (size_t)blockIdx.x * (BLOCK * ITEMS * S);
+    uint32_t cnt = 0;
+    float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
+    uint4 vw;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
+        unsigned m = (p.mode == 1) ? lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
+                                   : lane_mask<false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
+        cnt += __popc(m);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < WAVES; w++) t += wave_sum[w];
+        __hip_atomic_store(&block_counts[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t before = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = before == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next kernel that uses it
+    scan_block_counts<BLOCK>(block_counts, gridDim.x, total, tag);
+}
+
+// Exclusive scan of up to millions of block counts by ONE workgroup of 1024 lanes
+// (the count array is tiny: N/4096 entries).
+// The total goes to a pinned host word with `tag` in its upper half (one 64-bit store, no fence): the
+// host polls for the tag instead of waiting for the stream.
+__global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict__ counts, size_t nblocks, unsigned long long *__restrict__ total,
+                                                            uint32_t tag) {
+    scan_block_counts<1024>(counts, nblocks, total, tag);
+}
+
+template <int S>
 __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
                                                                const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
                                                                const uint32_t *__restrict__ block_offsets, float *__restrict__ ox,
                                                                float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
-    __shared__ uint32_t wave_sum[STEPS][WAVES];
+    __shared__ uint32_t wave_sum[S][WAVES];
     // every point kept (a tile filter on a cloud of that one tile, a crop box around everything): the host hands the input's
     // planes on as the result, nothing is copied
     if (block_offsets[gridDim.x] == n) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t tile0 = (size_t)blockIdx.x * TILE;
+    const size_t tile0 = (size_t)blockIdx.x * (BLOCK * ITEMS * S);
     const size_t out0 = block_offsets[blockIdx.x];
     // the whole tile is loaded before anything else happens (16 loads of 16 B per lane in flight);
     // the scatter needs all four planes of the kept points
-    float4 vx[STEPS], vy[STEPS], vz[STEPS];
-    uint4 vw[STEPS];
-    unsigned m[STEPS];
-    uint32_t inc[STEPS];
+    float4 vx[S], vy[S], vz[S];
+    uint4 vw[S];
+    unsigned m[S];
+    uint32_t inc[S];
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
+    for (int s = 0; s < S; s++) {
         const size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
         vx[s] = make_float4(0, 0, 0, 0); vy[s] = vx[s]; vz[s] = vx[s];
         vw[s] = make_uint4(0, 0, 0, 0);
@@ -248,7 +301,7 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
     }
     // ranks inside the tile (points run step-major, then lane-major): wave prefixes, one barrier
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
+    for (int s = 0; s < S; s++) {
         const uint32_t c = inc[s];
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = __shfl_up(inc[s], off, 64);
@@ -260,7 +313,7 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
     __syncthreads();
     uint32_t run = 0;
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
+    for (int s = 0; s < S; s++) {
         uint32_t before = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
@@ -301,8 +354,22 @@ static PredArgs to_args(const Predicate &p) {
 void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, hipStream_t s) {
     size_t nb = compact_blocks(src.npoints);
     if (!nb) return;
-    CW_LAUNCH("compact_count", compact_count_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(), src.rgbt(),
-              src.npoints, block_counts);
+    if (src.npoints <= SMALL_CLOUD) {
+        CW_LAUNCH("compact_count", compact_count_kernel<SMALL_STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(), src.rgbt(),
+                  src.npoints, block_counts);
+    } else {
+        CW_LAUNCH("compact_count", compact_count_kernel<STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(), src.rgbt(),
+                  src.npoints, block_counts);
+    }
+}
+
+bool compact_count_scan(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, uint32_t *ticket, unsigned long long *total_host, uint32_t tag,
+                        hipStream_t s) {
+    size_t nb = compact_blocks(src.npoints);
+    if (!nb || src.npoints > SMALL_CLOUD || !ticket) return false;   // (bigger clouds: the two launches)
+    CW_LAUNCH("compact_count", compact_count_scan_kernel<SMALL_STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(), src.rgbt(),
+              src.npoints, block_counts, ticket, total_host, tag);
+    return true;
 }
 
 void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *total_host, uint32_t tag, hipStream_t s) {
@@ -312,8 +379,13 @@ void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *to
 void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s) {
     size_t nb = compact_blocks(src.npoints);
     if (!nb) return;
-    CW_LAUNCH("compact_scatter", compact_scatter_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
-              src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt());
+    if (src.npoints <= SMALL_CLOUD) {
+        CW_LAUNCH("compact_scatter", compact_scatter_kernel<SMALL_STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+                  src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt());
+    } else {
+        CW_LAUNCH("compact_scatter", compact_scatter_kernel<STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+                  src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt());
+    }
 }
 
 // ---------------------------------------------------------------------------

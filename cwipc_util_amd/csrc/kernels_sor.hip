@@ -67,8 +67,16 @@ __device__ __forceinline__ void grid_dims(Grid &g, const double ext[3], double h
 }
 __device__ __forceinline__ size_t grid_cells(const Grid &g) { return (size_t)g.dim[0] * (size_t)g.dim[1] * (size_t)g.dim[2]; }
 
-// one wave: the cloud's box from the partial boxes, then the finest grid of at most cap_cells cells
-__global__ void __launch_bounds__(64) grid_setup_kernel(const float *__restrict__ partial, unsigned nb, size_t cap_cells, GridMeta *__restrict__ m) {
+// one wave of the first workgroup: the cloud's box from the partial boxes, then the finest grid of at most cap_cells cells
+// ... and the same launch clears the two per-cell arrays of the counting sort (its other workgroups: two memsets less)
+__global__ void __launch_bounds__(BLK) grid_setup_zero_kernel(const float *__restrict__ partial, unsigned nb, size_t cap_cells, GridMeta *__restrict__ m,
+                                                             uint32_t *__restrict__ counts, uint32_t *__restrict__ cursor) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const size_t nvec = cap_cells / 4;
+    uint4 *c4 = reinterpret_cast<uint4 *>(counts), *u4 = reinterpret_cast<uint4 *>(cursor);
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nvec; i += (size_t)gridDim.x * BLK) { c4[i] = zero; u4[i] = zero; }
+    if (blockIdx.x == 0 && threadIdx.x < (cap_cells & 3)) { counts[nvec * 4 + threadIdx.x] = 0; cursor[nvec * 4 + threadIdx.x] = 0; }
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (unsigned b = threadIdx.x; b < nb; b += 64)
         for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], partial[b * 6 + a]); hi[a] = fmaxf(hi[a], partial[b * 6 + 3 + a]); }
@@ -94,21 +102,21 @@ __global__ void __launch_bounds__(64) grid_setup_kernel(const float *__restrict_
     m->refine = 0;
 }
 
-// one lane: coarsen so that an occupied cell holds about `target` points (surface-like data: points per cell grow with h^2)
-__global__ void grid_refine_kernel(GridMeta *__restrict__ m, size_t n, double target) {
-    const double ppc = (double)n / (double)(m->occ ? m->occ : 1u);
+// The census says how many cells hold points (m->occ): coarsen the grid so that an occupied cell holds about `target` points
+// (surface-like data: points per cell grow with h^2) and, if so, clear the counts for the second count -- one launch: every
+// workgroup takes the decision from the same words (n, occ), the first one also writes the new grid (which nobody reads here).
+__global__ void __launch_bounds__(BLK) grid_refine_zero_kernel(GridMeta *__restrict__ m, size_t n, double target, uint32_t *__restrict__ words, size_t nwords) {
+    const uint32_t occ = m->occ;
+    const double ppc = (double)n / (double)(occ ? occ : 1u);
     if (!(ppc < target)) return;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nwords; i += (size_t)gridDim.x * BLK) words[i] = 0;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     double h = m->g.h * sqrt(target / ppc);
     if (h > m->maxext) h = m->maxext;
     Grid g = m->g;
     grid_dims(g, m->ext, h);
     m->g = g;
     m->refine = 1;
-}
-
-__global__ void __launch_bounds__(BLK) zero_if_refined_kernel(uint32_t *__restrict__ words, size_t nwords, const GridMeta *__restrict__ m) {
-    if (!m->refine) return;
-    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nwords; i += (size_t)gridDim.x * BLK) words[i] = 0;
 }
 
 __device__ __forceinline__ int cell_coord(const Grid &g, float v, int a) {
@@ -166,11 +174,14 @@ __device__ __forceinline__ WaveRun wave_run(uint32_t c, bool active) {
     return r;
 }
 
+// census: also count the cells that get their first point here (the adds then return what was there), one atomic per workgroup
+// on *census -- a separate pass over the whole cell array for it was a launch of its own
 __global__ void __launch_bounds__(BLK) cell_count_kernel(Grid gv, const GridMeta *__restrict__ gm, int second_count, const float *__restrict__ x,
                                                         const float *__restrict__ y, const float *__restrict__ z, size_t n, uint32_t *__restrict__ counts,
-                                                        uint32_t *__restrict__ cell_id) {
+                                                        uint32_t *__restrict__ cell_id, uint32_t *__restrict__ census) {
     if (gm && second_count && !gm->refine) return;   // the census's grid stands: its counts do too
     const Grid g = gm ? gm->g : gv;
+    uint32_t fresh = 0;
     for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
         const size_t i = base + threadIdx.x;
         const bool active = i < n;
@@ -180,7 +191,21 @@ __global__ void __launch_bounds__(BLK) cell_count_kernel(Grid gv, const GridMeta
             if (cell_id) cell_id[i] = c;
         }
         const WaveRun r = wave_run(c, active);
-        if (r.leads) atomicAdd(&counts[c], (uint32_t)r.length);
+        if (census) {
+            if (r.leads && atomicAdd(&counts[c], (uint32_t)r.length) == 0u) fresh++;
+        } else if (r.leads) {
+            atomicAdd(&counts[c], (uint32_t)r.length);
+        }
+    }
+    if (!census) return;
+    __shared__ uint32_t wsum[BLK / 64];
+    for (int off = 32; off > 0; off >>= 1) fresh += __shfl_down(fresh, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = fresh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < BLK / 64; w++) t += wsum[w];
+        if (t) atomicAdd(census, t);
     }
 }
 
@@ -403,6 +428,9 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
     return true;
 }
 
+// (Round 3, measured: a camera tile's 36 k queries take this kernel 39 us whether they sit 64 or 16 to a wave (567 or 2266 waves
+// on 1024 SIMDs): a query is ONE lane's chain of dependent loads -- row lookups, candidates four at a time -- and the kernel lasts
+// as long as such a chain, however many run side by side.  Several lanes per query would shorten it; not built.)
 // The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
 // compare-exchange chain, no LDS round trips per accepted candidate.  Unused leading slots hold -inf,
 // so the largest kept distance is always the last register.
@@ -604,15 +632,15 @@ bool sor_dense_on_device(const DeviceSoA &src, int k, float *dev_dist, float *pa
     }
     const Grid unused{};
     const unsigned cap_grid = std::min(1024u, grid_for(cap / 4 + 1));
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, c.stream, partial, nb, cap, meta);
-    bool ok = hipMemsetAsync(counts, 0, cap * sizeof(uint32_t), c.stream) == hipSuccess &&
-              hipMemsetAsync(cursor, 0, cap * sizeof(uint32_t), c.stream) == hipSuccess;
+    // (round 3: eleven launches instead of seventeen -- the two memsets ride with the grid's set-up, the census with the first
+    // count, the coarsening with the clearing it asks for; a camera tile's kernels cost the device less than their launches
+    // cost the host)
+    CW_LAUNCH("sor_grid_setup", grid_setup_zero_kernel, dim3(cap_grid), dim3(BLK), 0, c.stream, partial, nb, cap, meta, counts, cursor);
+    bool ok = true;
     if (ok) {
-        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, unused, meta, 0, src.x(), src.y(), src.z(), n, counts, cell_id);
-        CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(cap_grid), dim3(BLK), 0, c.stream, counts, cap, &meta->occ);
-        hipLaunchKernelGGL(grid_refine_kernel, dim3(1), dim3(1), 0, c.stream, meta, n, target);
-        hipLaunchKernelGGL(zero_if_refined_kernel, dim3(cap_grid), dim3(BLK), 0, c.stream, counts, cap, meta);
-        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, unused, meta, 1, src.x(), src.y(), src.z(), n, counts, cell_id);
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, unused, meta, 0, src.x(), src.y(), src.z(), n, counts, cell_id, &meta->occ);
+        CW_LAUNCH("sor_grid_refine", grid_refine_zero_kernel, dim3(cap_grid), dim3(BLK), 0, c.stream, meta, n, target, counts, cap);
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, unused, meta, 1, src.x(), src.y(), src.z(), n, counts, cell_id, (uint32_t *)nullptr);
         if (profiling_enabled()) profile_begin("sor_exclusive_scan", c.stream);
         e = rocprim::exclusive_scan(scan_tmp, tmp_bytes, counts, starts, 0u, cap, rocprim::plus<uint32_t>(), c.stream);
         if (profiling_enabled()) profile_end(c.stream);
@@ -816,7 +844,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess &&
          hipMemsetAsync(occ_dev, 0, sizeof(uint32_t), c.stream) == hipSuccess;
     if (ok) {
-        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, (const GridMeta *)nullptr, 0, src.x(), src.y(), src.z(), n, counts, cell_id);
+        CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, (const GridMeta *)nullptr, 0, src.x(), src.y(), src.z(), n, counts, cell_id, (uint32_t *)nullptr);
         CW_LAUNCH("sor_count_nonzero", count_nonzero_kernel, dim3(std::min(1024u, grid_for(ncells / 4 + 1))), dim3(BLK), 0, c.stream, counts, ncells, occ_dev);
         ok = hipMemcpyAsync(c.host_words, occ_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
     }
@@ -831,7 +859,7 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         g = make_grid(h);
         ncells = cells_of(g);
         ok = hipMemsetAsync(counts, 0, ncells * sizeof(uint32_t), c.stream) == hipSuccess;
-        if (ok) CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, (const GridMeta *)nullptr, 0, src.x(), src.y(), src.z(), n, counts, cell_id);
+        if (ok) CW_LAUNCH("sor_cell_count", cell_count_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, g, (const GridMeta *)nullptr, 0, src.x(), src.y(), src.z(), n, counts, cell_id, (uint32_t *)nullptr);
     }
 
     // 3. counting sort: exclusive scan of the counts, scatter
@@ -905,6 +933,9 @@ __global__ void __launch_bounds__(1024) stats_final_kernel(const double *__restr
     *thr = mean + (double)stddev_mul * stddev;
 }
 
+// (Both in one launch -- the workgroup that takes the last ticket runs the tree -- was built and measured in round 3: 29 us with a
+// ticket per partial sum, 16 us with sixteen partial sums per workgroup and ticket, against 3 + 3 us for the two kernels and the
+// boundary between them.  A compaction's count and scan in one launch do pay: kernels_basic.hip.)
 bool sor_threshold_device(const float *dev_dist, size_t n, float stddev_mul, double *thr_dev) {
     ThreadCtx &c = tctx();
     if (!c.ensure()) return false;
