@@ -44,7 +44,8 @@ def test_committed_profile_files_are_from_one_run():
     assert len(k1) == 1, [r["Name"] for r in k1]
     avg_csv = float(k1[0]["AverageNs"])
     summary = open(os.path.join(prof, newest + "_bench_rocprofv3_summary.txt")).read()
-    m = re.search(r"^\S*voxel_accumulate\S*.*?\s+(\d+)\s+(\d+)\s+(\d+)\s+\d+\s+\d+\s+[\d.]+\s*$", summary, re.M)
+    # (the kernel's name as the csv has it -- "void cwipc_amd::(anonymous namespace)::voxel_accumulate_fast_kernel<1>..." -- holds blanks)
+    m = re.search(r"^[^\n]*voxel_accumulate(?!_general)[^\n]*?\s+(\d+)\s+(\d+)\s+(\d+)\s+\d+\s+\d+\s+[\d.]+\s*$", summary, re.M)
     assert m, "no accumulate-kernel row in the summary"
     assert int(m.group(1)) == int(k1[0]["Calls"]) and abs(int(m.group(3)) - avg_csv) <= 1.0, (m.groups(), avg_csv)
     assert "# bench line under the profiler:" in summary
