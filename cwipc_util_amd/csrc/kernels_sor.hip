@@ -430,7 +430,8 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
 
 // (Round 3, measured: a camera tile's 36 k queries take this kernel 39 us whether they sit 64 or 16 to a wave (567 or 2266 waves
 // on 1024 SIMDs): a query is ONE lane's chain of dependent loads -- row lookups, candidates four at a time -- and the kernel lasts
-// as long as such a chain, however many run side by side.  Several lanes per query would shorten it; not built.)
+// as long as such a chain, however many run side by side.  Eight candidate loads in flight instead of four: 41 us, no change
+// either (sixteen, through an array the compiler put into scratch memory: 149 us).  Several lanes per query would shorten it; not built.)
 // The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
 // compare-exchange chain, no LDS round trips per accepted candidate.  Unused leading slots hold -inf,
 // so the largest kept distance is always the last register.
