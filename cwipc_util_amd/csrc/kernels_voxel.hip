@@ -1837,8 +1837,6 @@ struct PendingVoxel : DeferredResult {
     uint32_t scatter = 0, steps_total = 0;       //   ... and this is how scattered the cloud was as it came (of how many wave steps)
     uint32_t leaves = 0;                         // leaf grids the pass used
     bool outcome_locked();                       // waits for the replay kernel's report; true: spec_dst holds the result
-    // has the replay kernel's report come in (no waiting, no lock: one word of pinned memory)?
-    bool arrived() const { return known || (words && (uint32_t)(words[C_COUNT] >> 32) == seq); }
     bool outcome() { std::lock_guard<std::recursive_mutex> g(lock); return outcome_locked(); }
     std::shared_ptr<DeviceSoA> settle() override;
 };
@@ -1962,9 +1960,18 @@ struct WorkspaceLease {
     ~WorkspaceLease() {
         // thread exit: a finalize kernel of this thread's last call may still be using a workspace
         if (ws[0] || ws[1]) (void)hipDeviceSynchronize();
-        std::lock_guard<std::mutex> lock(g_ws_pool_mutex);
-        for (int i = 0; i < 2; i++)
-            if (ws[i]) g_ws_pool->push_back(ws[i]);
+        // (r3: at most eight wait here -- a program with a thread per tile and frame finds one each; what threads held beyond
+        // that, mostly second workspaces that a busy moment made them take, is given back to the device)
+        std::vector<Workspace *> surplus;
+        {
+            std::lock_guard<std::mutex> lock(g_ws_pool_mutex);
+            for (int i = 0; i < 2; i++) {
+                if (!ws[i]) continue;
+                if (g_ws_pool->size() < 8) g_ws_pool->push_back(ws[i]);
+                else surplus.push_back(ws[i]);
+            }
+        }
+        for (Workspace *w : surplus) delete w;
     }
 };
 thread_local WorkspaceLease t_ws;
@@ -2155,13 +2162,11 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     // that one's finalize kernel.  The second one comes into being only when it is needed: a thread whose downsample calls
     // are separated by other work (a per-tile filter chain) finds its first workspace idle every time and never pays the
     // 80+ MB of grids for a second.
-    // (r3: "needed" = the first workspace's own last pass has not reported yet -- downsample calls back to back -- not "the
-    // thread's stream is busy", which in a filter chain it nearly always is, with the filter before: under load some threads of
-    // an eight-thread chain got a second workspace that way, 0.3 GB each)
     int which = t_ws_next;
     if (!t_ws.ws[1]) {
         which = 0;
-        if (t_ws.ws[0] && t_ws.ws[0]->pending && !t_ws.ws[0]->pending->arrived()) which = 1;
+        if (t_ws.ws[0] && c.stream && hipStreamQuery(c.stream) == hipErrorNotReady) which = 1;
+        (void)hipGetLastError();   // (hipErrorNotReady is an answer, not a failure)
     } else if (c.stream && c.stream_alt && !t_ws.ws[1]->pending) {
         // ... and goes again when it has not been needed for a while: sixteen calls in a row that found both streams idle (a
         // thread that has stopped calling back to back: 0.3 GB of leaf grids it no longer needs)
