@@ -261,7 +261,7 @@ bool ThreadCtx::ensure() {
     if (!host_words) CW_HIP_TRY(hipHostMalloc((void **)&host_words, 64 * sizeof(uint32_t), hipHostMallocDefault));
     CW_HIP_TRY(hipMalloc(&dev_words, 64 * sizeof(uint32_t)));
     CW_HIP_TRY(hipMalloc((void **)&tickets, 16 * sizeof(uint32_t)));
-    CW_HIP_TRY(hipMemsetAsync(tickets, 0, 16 * sizeof(uint32_t), stream));
+    CW_HIP_TRY(hipMemset(tickets, 0, 16 * sizeof(uint32_t)));   // (once per thread; done before any of the thread's streams uses them)
     return true;
 }
 

@@ -431,7 +431,13 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
 // (Round 3, measured: a camera tile's 36 k queries take this kernel 39 us whether they sit 64 or 16 to a wave (567 or 2266 waves
 // on 1024 SIMDs): a query is ONE lane's chain of dependent loads -- row lookups, candidates four at a time -- and the kernel lasts
 // as long as such a chain, however many run side by side.  Eight candidate loads in flight instead of four: 41 us, no change
-// either (sixteen, through an array the compiler put into scratch memory: 149 us).  Several lanes per query would shorten it; not built.)
+// either (sixteen, through an array the compiler put into scratch memory: 149 us).  FOUR LANES PER QUERY (each scans every fourth
+// candidate into a list of its own, the lists merged by two butterfly steps over the quad, rows and rings turned away on a bound
+// the quad shares; d_i bit-identical, all tests green): 50 us.  The rows of a ring beyond the first looked up eight at a time
+// instead of one after the other: 44 us.  So it is neither the candidates nor the row lookups one by one: per wave the counters
+// say 4400 vector instructions (7 us), 182 loads and 52 % of 22 us waiting, the slowest waves twice that; what the waves wait
+// for are first touches of the sorted points and the cell arrays, which the kernels before have just written from all eight
+// XCDs (a cold L2 for every line).  Not resolved in round 3.)
 // The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
 // compare-exchange chain, no LDS round trips per accepted candidate.  Unused leading slots hold -inf,
 // so the largest kept distance is always the last register.
