@@ -454,6 +454,24 @@ def test_downsample_cellsizes(gpu, oracle, synth, cellsize):
     check_downsample(gpu, oracle, pts, cs, -cellsize)
 
 
+@pytest.mark.parametrize("tiles", ["zero", "high_bits", "mixed"])
+@pytest.mark.parametrize("cellsize", [0.01, -0.01])
+def test_downsample_tile_bits_of_every_kind(gpu, oracle, synth, tiles, cellsize):
+    """A voxel's tile is the OR of its points' tiles.  The fast accumulate kernel's flush sends a record word only if it has
+    something to add (csrc/voxel_k1_fast.inc): clouds whose tiles are all 0 (neither tile word is sent), all in bits 4-7 (only
+    the second one), and a mixture inside voxels and across workgroups (2 M points: a voxel's points lie in several ranges)."""
+    pts, cs = synth(2_000_000)
+    pts = pts.copy()
+    n = len(pts)
+    if tiles == "zero":
+        pts['tile'] = 0
+    elif tiles == "high_bits":
+        pts['tile'] = np.where(np.arange(n) < n // 2, 0x10, 0xa0).astype(np.uint8)
+    else:
+        pts['tile'] = np.array([0, 0x10, 3, 0x84, 1, 0, 0x40, 2], dtype=np.uint8)[(np.arange(n) // 1000) % 8]
+    check_downsample(gpu, oracle, pts, cs, cellsize)
+
+
 def test_downsample_reference_loop(gpu, synth):
     """reference test_downsample / test_downsample_voxelgrid: doubling cellsize ends with <= 8 points."""
     pts, cs = synth(0)
