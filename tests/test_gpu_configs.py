@@ -221,10 +221,15 @@ def test_config5_eight_threads_workspace_footprint(gpu):
     sized from what the thread's clouds need and shrink again after eight roomy passes.  A tile of this capture is the whole
     synthetic figure (12 to 16 octree leaves of 0.64 m at 1 cm), so a workspace is 16 grids = 0.32 GB: eight threads and this
     one hold ~3.2 GB.  Round 1 held 21 GB here (64 grids x 2 workspaces per thread)."""
+    import gc
     import threading
     from cwipc_util_amd.capture import capture_tile
     from cwipc_util_amd.filters import factory
     dll = gpu.util.cwipc_util_dll_load()
+    # (what threads of earlier tests still hold -- an executor's workers live until they are collected -- is theirs, not this test's)
+    gc.collect()
+    dll.cwipc_hip_synchronize()
+    held_before = dll.cwipc_hip_workspace_bytes()
     tiles = [capture_tile(300_000, t, NTILES) for t in range(NTILES)]
     counts, errors = {}, []
 
@@ -251,7 +256,8 @@ def test_config5_eight_threads_workspace_footprint(gpu):
         gpu.cwipc_downsample(tiles[0], 0.01).count()
     dll.cwipc_hip_synchronize()
     held = dll.cwipc_hip_workspace_bytes()
-    assert held <= 3.5 * 10**9, held
+    # eight threads' workspaces of 16 grids (0.32 GB each) on top of what was there, or ten in all when nothing was
+    assert held <= max(3.5 * 10**9, held_before + 2.7 * 10**9), (held, held_before)
 
 
 @pytest.fixture(scope="module")
