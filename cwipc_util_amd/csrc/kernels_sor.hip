@@ -436,8 +436,8 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
 // the quad shares; d_i bit-identical, all tests green): 50 us.  The rows of a ring beyond the first looked up eight at a time
 // instead of one after the other: 44 us.  So it is neither the candidates nor the row lookups one by one: per wave the counters
 // say 4400 vector instructions (7 us), 182 loads and 52 % of 22 us waiting, the slowest waves twice that; what the waves wait
-// for are first touches of the sorted points and the cell arrays, which the kernels before have just written from all eight
-// XCDs (a cold L2 for every line).  Not resolved in round 3.)
+// for is not a cold L2 either (the arrays have just been written from all eight XCDs, but the same kernel launched a second
+// time right behind the first takes 37.8 us against 42.4).  Not resolved in round 3.)
 // The same search with the candidate list in registers (k + 1 <= KCAP): a sorted list kept by a
 // compare-exchange chain, no LDS round trips per accepted candidate.  Unused leading slots hold -inf,
 // so the largest kept distance is always the last register.
