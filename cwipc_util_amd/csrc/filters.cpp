@@ -213,10 +213,10 @@ extern "C" cwipc_pointcloud *cwipc_tilemap(cwipc_pointcloud *pc, uint8_t map[256
     if (!ok) return nullptr;
     inherit_first(*dst, *src);
     {   // the tiles that may occur afterwards: the images of those that may occur now (of all 256 values if nothing is known)
-        dst->has_tiles = true;
-        for (int i = 0; i < 8; i++) dst->tiles[i] = 0;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (unsigned t = 0; t < 256; t++)
-            if (src->may_have_tile(t)) dst->tiles[map[t] >> 5] |= 1u << (map[t] & 31u);
+            if (src->may_have_tile(t)) w[map[t] >> 5] |= 1u << (map[t] & 31u);
+        dst->set_tiles(w);
     }
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
@@ -235,10 +235,10 @@ extern "C" cwipc_pointcloud *cwipc_colormap(cwipc_pointcloud *pc, uint32_t clear
     if (!c.sync()) return nullptr;
     inherit_first(*dst, *src);
     if (src->has_tiles) {   // the tile is bits 24-31 of the word the masks work on (:377-378)
-        dst->has_tiles = true;
-        for (int i = 0; i < 8; i++) dst->tiles[i] = 0;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (unsigned t = 0; t < 256; t++)
-            if (src->may_have_tile(t)) { const unsigned u = ((t & ~(clearBits >> 24)) | (setBits >> 24)) & 255u; dst->tiles[u >> 5] |= 1u << (u & 31u); }
+            if (src->may_have_tile(t)) { const unsigned u = ((t & ~(clearBits >> 24)) | (setBits >> 24)) & 255u; w[u >> 5] |= 1u << (u & 31u); }
+        dst->set_tiles(w);
     }
     return wrap(dst, pc->timestamp(), pc->cellsize());
 }
@@ -298,8 +298,13 @@ extern "C" int cwipc_hip_tiles_used(cwipc_pointcloud *pc, uint8_t *used256) {
         used256[t] = (c.host_words[t >> 5] >> (t & 31)) & 1u;
         count += used256[t];
     }
-    src->has_tiles = true;   // (a census: remembered on the cloud)
-    for (int w = 0; w < 8; w++) src->tiles[w] = c.host_words[w];
+    // a census: remembered on the cloud.  The cloud may be in other threads' hands (clouds are immutable but for this note): one
+    // census at a time writes the words, and only a cloud that has no set yet gets one (a set a producer left is at least as good)
+    {
+        static std::mutex census_mutex;
+        std::lock_guard<std::mutex> lock(census_mutex);
+        if (!src->has_tiles.load(std::memory_order_acquire)) src->set_tiles(c.host_words);
+    }
     return count;
 }
 
@@ -406,7 +411,7 @@ extern "C" cwipc_pointcloud *cwipc_hip_join_multi(cwipc_pointcloud **pcs, int np
             known = known && src[i]->has_tiles;
             for (int w = 0; w < 8; w++) u[w] |= src[i]->tiles[w];
         }
-        if (known) { dst->has_tiles = true; for (int w = 0; w < 8; w++) dst->tiles[w] = u[w]; }
+        if (known) dst->set_tiles(u);
     }
     return wrap(dst, ts, cellsize);
 }

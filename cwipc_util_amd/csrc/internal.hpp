@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstddef>
+#include <atomic>
 #include <memory>
 #include <utility>
 #include <mutex>
@@ -155,13 +156,16 @@ struct DeviceSoA {
     // a join takes the union.  A one-element set on a cloud with points says that EVERY point has that tile: cwipc_tilefilter
     // for it hands the planes on without looking at a point (a camera's tile is filtered by its own mask in the per-tile chain
     // of the reference, python/cwipc/registration/util.py:170-182), and a filter for a value outside the set is empty.
-    mutable bool has_tiles = false;
+    // Producers fill the set before they publish the cloud; a census (cwipc_hip_tiles_used) adds it to a cloud other threads may be
+    // filtering at that moment: the words first, then the flag with release order, and readers take the flag with acquire order.
+    mutable std::atomic<bool> has_tiles{false};
     mutable uint32_t tiles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    void set_tiles_from(const DeviceSoA &o) const { has_tiles = o.has_tiles; for (int i = 0; i < 8; i++) tiles[i] = o.tiles[i]; }
-    void set_one_tile(unsigned t) const { has_tiles = true; for (int i = 0; i < 8; i++) tiles[i] = 0; tiles[(t & 255u) >> 5] = 1u << (t & 31u); }
-    bool may_have_tile(unsigned t) const { return !has_tiles || t > 255u || ((tiles[t >> 5] >> (t & 31u)) & 1u) != 0u; }
+    void set_tiles(const uint32_t words[8]) const { for (int i = 0; i < 8; i++) tiles[i] = words[i]; has_tiles.store(true, std::memory_order_release); }
+    void set_tiles_from(const DeviceSoA &o) const { if (o.has_tiles.load(std::memory_order_acquire)) set_tiles(o.tiles); else has_tiles.store(false, std::memory_order_release); }
+    void set_one_tile(unsigned t) const { uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0}; w[(t & 255u) >> 5] = 1u << (t & 31u); set_tiles(w); }
+    bool may_have_tile(unsigned t) const { return !has_tiles.load(std::memory_order_acquire) || t > 255u || ((tiles[t >> 5] >> (t & 31u)) & 1u) != 0u; }
     bool only_tile(unsigned t) const {
-        if (!has_tiles || t > 255u) return false;
+        if (!has_tiles.load(std::memory_order_acquire) || t > 255u) return false;
         for (int i = 0; i < 8; i++) if (tiles[i] != (i == (int)(t >> 5) ? 1u << (t & 31u) : 0u)) return false;
         return true;
     }

@@ -401,17 +401,30 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
     *slab = nullptr;
     const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
     const size_t shmem = (size_t)(k + 1) * QB * sizeof(float);
-    if (shmem <= (size_t)160 * 1024 - 512) {
-        if (shmem > (size_t)64 * 1024) {
-            static std::mutex once;
-            static int raised_on = -1;
-            std::lock_guard<std::mutex> g(once);
-            if (raised_on != current_device()) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mean_dist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
-                    return hip_failed(hipGetLastError(), "sor k-NN LDS limit", __FILE__, __LINE__);
-                raised_on = current_device();
+    // (a device whose LDS limit cannot be raised that far -- the attribute call fails, or the device reports less -- takes the slab
+    // path below for these k as well: any kNeighbors works, as in the reference)
+    bool in_lds = shmem <= (size_t)160 * 1024 - 512;
+    if (in_lds && shmem > (size_t)64 * 1024) {
+        static std::mutex once;
+        static int raised_on = -1, refused_on = -1;
+        std::lock_guard<std::mutex> g(once);
+        const int dev = current_device();
+        if (refused_on == dev) {
+            in_lds = false;
+        } else if (raised_on != dev) {
+            int lds_max = 0;
+            if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); lds_max = 0; }
+            if (lds_max >= 160 * 1024 - 512 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mean_dist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess) {
+                raised_on = dev;
+            } else {
+                (void)hipGetLastError();
+                refused_on = dev;
+                in_lds = false;
             }
         }
+    }
+    if (in_lds) {
         CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_kernel, dim3(qgrid), dim3(QB), shmem, s, gv, gm, sorted, n, cell_start, cell_count, k, dist_out, (float *)nullptr);
         return true;
     }

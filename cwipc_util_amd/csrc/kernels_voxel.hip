@@ -1960,6 +1960,12 @@ struct WorkspaceLease {
     ~WorkspaceLease() {
         // thread exit: a finalize kernel of this thread's last call may still be using a workspace
         if (ws[0] || ws[1]) (void)hipDeviceSynchronize();
+        // A pass of this thread that was handed out while it ran (ws.pending) reads its report from the workspace's pinned words
+        // when somebody asks for the result -- possibly another thread, long after this one has gone and the workspace with
+        // it.  The report is final now: take it (the outcome is cached in the pending pass, the words are not looked at again).
+        // A workspace that goes to the pool keeps its `pending`: its next user learns from it whether the records were left clean.
+        for (int i = 0; i < 2; i++)
+            if (ws[i] && ws[i]->pending) (void)ws[i]->pending->outcome();
         // (r3: at most eight wait here -- a program with a thread per tile and frame finds one each; what threads held beyond
         // that, mostly second workspaces that a busy moment made them take, is given back to the device)
         std::vector<Workspace *> surplus;
@@ -2002,8 +2008,12 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         const int lds_fast = (int)sizeof(FastTable);
-        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
-        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<0, K1_THREADS, LTAB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<1, K1_THREADS, LTAB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast));
+        const int lds_pair = (int)sizeof(PairTable);
+        static_assert(2 * sizeof(PairTable) <= 160 * 1024, "two workgroups of the paired accumulate kernel share a CU's LDS");
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<0, PAIR_THREADS, PAIR_LTAB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pair));
+        CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_accumulate_fast_kernel<1, PAIR_THREADS, PAIR_LTAB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pair));
         CW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&partition_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         ws.device = dev;
     }
@@ -2429,23 +2439,35 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             // The workgroups' ranges: the cloud's steps dealt evenly over the CUs the grid may use (a workgroup's waves share its
             // range step by step, so a range need not be a multiple of sixteen steps): a 300 k-point cloud gets 235 workgroups
             // of 5 steps, five busy waves each, instead of 74 workgroups whose sixteen waves queue up on four SIMDs.
-            const size_t wg_steps = std::min<size_t>(std::max<size_t>((steps_total + (size_t)cus - 1) / (size_t)cus, 1), MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP);
+            // r4: two workgroups of 8 waves per CU (voxel_k1_fast.inc), each with half the range, taken in two sub-ranges with a flush
+            // after each; CWIPC_K1_PAIR=0: one workgroup of 16 waves per CU as in rounds 2 and 3, =2: sub-ranges by workgroup number
+            static const int pair_knob = []() { const char *e = getenv("CWIPC_K1_PAIR"); return e ? atoi(e) : 1; }();
+            const bool pair = pair_knob != 0;
+            const size_t slots = (size_t)cus * (pair ? 2 : 1);
+            const size_t wg_steps = std::min<size_t>(std::max<size_t>((steps_total + slots - 1) / slots, 1), MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP);
             fast_blocks = (uint32_t)((steps_total + wg_steps - 1) / wg_steps);
             fast_per_wg = (uint32_t)(wg_steps * WAVE_STEP);
             F.n = K.n; F.per_wg = fast_per_wg; F.inv_leaf = K.inv_leaf;
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
+            F.split = pair ? (pair_knob == 2 ? 2u : pair_knob == 3 ? 0u : 1u) : 0u;
 #ifdef CWIPC_DEBUG_KNOBS
             static const uint32_t fast_dbg = []() { const char *e = getenv("CWIPC_FAST_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
             if (fast_dbg) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_FAST_DBG is set: results are WRONG (timing experiments only)");
             F.dbg = fast_dbg;
 #endif
-            if (mode == 0) {
-                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<0>, dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+            if (pair && mode == 0) {
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), sizeof(PairTable), c.stream, F,
+                          src.x(), src.y(), src.z(), src.rgbt(), W);
+            } else if (pair) {
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), sizeof(PairTable), c.stream, F,
+                          src.x(), src.y(), src.z(), src.rgbt(), W);
+            } else if (mode == 0) {
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
             } else {
-                CW_LAUNCH("voxel_accumulate", voxel_accumulate_fast_kernel<1>, dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
             }
         } else if (mode == 0) {

@@ -189,8 +189,8 @@ private:
         const float pi = 3.14159265358979f;
         const bool eyes_white = fmod((double)m_angle, (double)(pi / 2)) > 0.08;   // reference :209
         k::synthetic_fill(*dst, m_hsteps, m_asteps, m_angle, eyes_white, radius, height, angle, sin_a, cos_a, c.stream);
-        dst->has_tiles = true;   // tile = (y < 0) ? 1 : 2 (reference src/cwipc_synthetic.cpp:218)
-        dst->tiles[0] = 6u;
+        const uint32_t both[8] = {6u, 0, 0, 0, 0, 0, 0, 0};   // tile = (y < 0) ? 1 : 2 (reference src/cwipc_synthetic.cpp:218)
+        dst->set_tiles(both);
         if (!c.sync()) return nullptr;
         dst->first[0] = m_first[0]; dst->first[1] = m_first[1]; dst->first[2] = m_first[2];
         dst->has_first = true;
