@@ -41,7 +41,7 @@ SOURCES = [
 COMMON_FLAGS = [
     "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
     "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
-    "-DCWIPC_VERSION=amd-gfx950-r2",
+    "-DCWIPC_VERSION=amd-gfx950-r4",
     "-I" + os.path.join(REPO_DIR, "include"), "-I" + SRC_DIR,
 ]
 

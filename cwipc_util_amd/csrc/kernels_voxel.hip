@@ -160,6 +160,8 @@ struct VoxWork {
     uint32_t *seg_count;             // [leaf hash][RANK_SEGS] occupied cells per bitmap slice (accumulated by K1's flush)
     unsigned long long *hash_keys;   // [4 x leaf grids] leaf -> id: open addressing on the packed coordinates ...
     uint32_t *hash_ids;              //   ... and the id + 1 of the entry's leaf (0: not published yet, ~0: no grid left)
+    uint32_t *dump_head;             // r4, fast accumulate kernel with FastParams::dump: per workgroup a DumpHead ...
+    uint32_t *dump_ent;              //   ... and room for the entries of its table, DUMP_ENTRY_WORDS words each (voxel_k1_fast.inc)
 };
 
 inline __host__ __device__ uint64_t mix64(uint64_t k) {
@@ -1891,6 +1893,8 @@ struct Workspace {
     uint32_t *gprefix = nullptr, *gblock = nullptr;
     size_t gwords_cap = 0;
     float *bboxes = nullptr;           // [2][bbox_cap][6]: the ranges' boxes the replay kernel reads; behind them room for boxes nobody reads
+    uint32_t *dump_head = nullptr, *dump_ent = nullptr;   // what the fast accumulate kernel leaves for the merge kernel (r4) ...
+    size_t dump_blocks = 0, dump_entries = 0;             //   ... for this many workgroups of this many table entries
     float *part = nullptr;             // partition pass: the cloud moved into spatial buckets, four planes of part_stride elements
     size_t part_stride = 0;
     uint32_t *part_hist = nullptr;     //   ... and its PART_BUCKETS bucket counts / cursors
@@ -1907,8 +1911,14 @@ struct Workspace {
         if (part_hist) (void)hipFree(part_hist);
         part = nullptr; part_hist = nullptr; part_stride = 0;
     }
+    void drop_dump_buffers() {
+        if (dump_head) (void)hipFree(dump_head);
+        if (dump_ent) { (void)hipFree(dump_ent); g_workspace_bytes -= dump_blocks * dump_entries * DUMP_ENTRY_WORDS * 4; }
+        dump_head = dump_ent = nullptr; dump_blocks = dump_entries = 0;
+    }
     void release() {
         // also runs at thread exit, when the runtime may be gone: errors ignored
+        drop_dump_buffers();
         if (head) (void)hipFree(head);
         if (records) (void)hipFree(records);
         if (occupied) (void)hipFree(occupied);
@@ -2207,7 +2217,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             if (p->leaf_split) ws.last_m = 0; else ws.last_m_grid = 0;
             ws.streak = 0;
             if (p->err & (ERR_FAST_PATH | ERR_CELL_RANGE)) ws.no_fast = true;
-            VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
+            VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids, ws.dump_head, ws.dump_ent};
             CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
             if (!c.sync()) { hip_failed(hipGetLastError(), "voxel workspace clean-up", __FILE__, __LINE__); return nullptr; }
         }
@@ -2378,7 +2388,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.seg_count = (uint32_t *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8);
         ws.hash_keys = (unsigned long long *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8 + (size_t)ws.leaf_cap * RANK_SEGS * sizeof(uint32_t));
         ws.hash_ids = (uint32_t *)((char *)ws.hash_keys + (size_t)ws.leaf_cap * 4 * 8);
-        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
+        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids, ws.dump_head, ws.dump_ent};
         bool ok = true;
         if (!ws.head_clean[blk]) ok = hipMemsetAsync(head, 0, ws.head_bytes, c.stream) == hipSuccess;
         ws.head_clean[blk] = false;
@@ -2439,9 +2449,8 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             // The workgroups' ranges: the cloud's steps dealt evenly over the CUs the grid may use (a workgroup's waves share its
             // range step by step, so a range need not be a multiple of sixteen steps): a 300 k-point cloud gets 235 workgroups
             // of 5 steps, five busy waves each, instead of 74 workgroups whose sixteen waves queue up on four SIMDs.
-            // r4: two workgroups of 8 waves per CU (voxel_k1_fast.inc), each with half the range, taken in two sub-ranges with a flush
-            // after each; CWIPC_K1_PAIR=0: one workgroup of 16 waves per CU as in rounds 2 and 3, =2: sub-ranges by workgroup number
-            static const int pair_knob = []() { const char *e = getenv("CWIPC_K1_PAIR"); return e ? atoi(e) : 1; }();
+            // CWIPC_K1_PAIR=1 (experiments): two workgroups of 8 waves and half the range per CU instead of one of 16 (voxel_k1_fast.inc)
+            static const int pair_knob = []() { const char *e = getenv("CWIPC_K1_PAIR"); return e ? atoi(e) : 0; }();
             const bool pair = pair_knob != 0;
             const size_t slots = (size_t)cus * (pair ? 2 : 1);
             const size_t wg_steps = std::min<size_t>(std::max<size_t>((steps_total + slots - 1) / slots, 1), MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP);
@@ -2451,24 +2460,55 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
-            F.split = pair ? (pair_knob == 2 ? 2u : pair_knob == 3 ? 0u : 1u) : 0u;
+            // r4, measured and NOT the default (profiles/r04_k1_dump_merge.txt): CWIPC_K1_DUMP=1 makes the accumulate kernel leave its
+            // tables' entries in the workspace, and a kernel of small workgroups right behind it takes them to the records
+            // (voxel_k1_fast.inc, fast_dump / voxel_merge_kernel).  The accumulate kernel alone: 53.4 -> 48.1 us; but the records'
+            // 112 k x 6 atomics, sent by all the merge workgroups at once, take the memory side as long as they take wherever they
+            // come from (merge kernel 20 us alone), a single call with count() 64.6 -> 78.7 us, a call in a stream 54.6 -> 60-69 us
+            // (the merge workgroups find no room beside the next call's accumulate kernel: 4 x 112 of a SIMD's 512 registers are taken)
+            static const bool dump_knob = []() { const char *e = getenv("CWIPC_K1_DUMP"); return e && atoi(e) != 0; }();
+            const size_t table_entries = pair ? (size_t)PAIR_LTAB : (size_t)LTAB;
+            bool dump = dump_knob;
+            if (dump && (ws.dump_blocks < fast_blocks || ws.dump_entries != table_entries)) {
+                ws.drop_dump_buffers();
+                const size_t blocks_cap = std::max<size_t>(fast_blocks, 256);
+                if (hipMalloc((void **)&ws.dump_head, blocks_cap * sizeof(DumpHead)) != hipSuccess ||
+                    hipMalloc((void **)&ws.dump_ent, blocks_cap * table_entries * DUMP_ENTRY_WORDS * 4) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (ws.dump_head) (void)hipFree(ws.dump_head);
+                    ws.dump_head = ws.dump_ent = nullptr;
+                    dump = false;   // no room for the tables: this pass updates the records from the accumulate kernel
+                } else {
+                    ws.dump_blocks = blocks_cap; ws.dump_entries = table_entries;
+                    g_workspace_bytes += blocks_cap * table_entries * DUMP_ENTRY_WORDS * 4;
+                }
+            }
+            W.dump_head = ws.dump_head; W.dump_ent = ws.dump_ent;
+            F.dump = dump ? 1u : 0u;
 #ifdef CWIPC_DEBUG_KNOBS
             static const uint32_t fast_dbg = []() { const char *e = getenv("CWIPC_FAST_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
             if (fast_dbg) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_FAST_DBG is set: results are WRONG (timing experiments only)");
             F.dbg = fast_dbg;
 #endif
+            // (a workgroup that leaves its table needs the LDS up to the list of entries in use only: 105 instead of 151 KB)
+            const size_t lds_pair = dump ? PairTable::DUMP_LDS_BYTES : sizeof(PairTable), lds_one = dump ? FastTable::DUMP_LDS_BYTES : sizeof(FastTable);
             if (pair && mode == 0) {
-                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), sizeof(PairTable), c.stream, F,
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), lds_pair, c.stream, F,
                           src.x(), src.y(), src.z(), src.rgbt(), W);
             } else if (pair) {
-                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), sizeof(PairTable), c.stream, F,
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), lds_pair, c.stream, F,
                           src.x(), src.y(), src.z(), src.rgbt(), W);
             } else if (mode == 0) {
-                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), lds_one, c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
             } else {
-                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), sizeof(FastTable), c.stream, F, src.x(),
+                CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), lds_one, c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
+            }
+            if (dump && mode == 0) {
+                CW_LAUNCH("voxel_merge", voxel_merge_kernel<0>, dim3(fast_blocks), dim3(MERGE_THREADS), 0, c.stream, F, (uint32_t)table_entries, W);
+            } else if (dump) {
+                CW_LAUNCH("voxel_merge", voxel_merge_kernel<1>, dim3(fast_blocks), dim3(MERGE_THREADS), 0, c.stream, F, (uint32_t)table_entries, W);
             }
         } else if (mode == 0) {
             CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);

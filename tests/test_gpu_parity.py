@@ -874,7 +874,8 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
             assert same(got, np.load(os.path.join(tmp, "out_%s.npy" % c))), c
 
 
-@pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0"])
+@pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0",
+                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_PAIR=1"])
 def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
     """Every environment knob of the shipped library selects another way to the same result: a
     process with the knob set must produce, bit for bit, what this process produces -- a stream of downsample calls (the
