@@ -205,6 +205,28 @@ bool gather_words(cwipc_hip_comm *cm, const void *mine_host, void *mine_dev, voi
     return ok;
 }
 
+#ifdef CWIPC_EXCHANGE_TEST_HOOKS
+// TEST BUILD ONLY (tests/standin/build_standin.py compiles this file a second time with the macro; the shipped library is built
+// without it): faults on chosen frames of chosen ranks, so that the branches of join_frame that need a rank in trouble -- a rank
+// that takes no part (ST_ABSENT), a rank that cannot allocate its fused cloud between the gathers (ST_NO_RECV), a rank that holds
+// no room yet (a second gather round where only some ranks allocate) -- issue their real sends and receives.
+// CWIPC_TEST_EXCHANGE_FAULTS="rank:frame:bits,..." with bits 1: no device context, 2: the allocation of round 1b fails, 4: no room
+// is taken before the gather.
+uint32_t test_fault(int rank, unsigned long long frame) {
+    const char *e = getenv("CWIPC_TEST_EXCHANGE_FAULTS");
+    uint32_t bits = 0;
+    while (e && *e) {
+        int r = -1; unsigned long long f = 0; unsigned b = 0; int used = 0;
+        if (sscanf(e, "%d:%llu:%u%n", &r, &f, &b, &used) >= 3 && r == rank && f == frame) bits |= b;
+        const char *comma = strchr(e, ',');
+        e = comma ? comma + 1 : nullptr;
+    }
+    return bits;
+}
+#else
+inline uint32_t test_fault(int, unsigned long long) { return 0; }
+#endif
+
 // One frame's exchange, once this rank's part is known: `src` are its planes (nullptr: no tile this frame, or a tile that
 // could not be read -- bad_input -- which the other ranks see as "no tile" while this rank's call fails).  The caller holds
 // cm->lock.
@@ -219,7 +241,8 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
     const bool wire = W > 1 || loopback;
     ThreadCtx &c = tctx();
     uint32_t my_status = xplan::ST_OK;
-    if (!c.ensure()) {
+    const uint32_t fault = test_fault(cm->rank, cm->frames);   // (0 in the shipped library)
+    if (!c.ensure() || (fault & 1u)) {
         my_status = xplan::ST_ABSENT;   // (logged by ensure)
     } else if (current_device() != cm->device) {
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "the communicator was made for another device: this rank's tile is left out of the frame");
@@ -234,7 +257,7 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
     // has to allocate between the gather and the payload (and nobody can fail there unseen)
     std::shared_ptr<DeviceSoA> room;
     size_t room_points = 0;
-    if (wire && my_status == xplan::ST_OK && cm->expect_points) {
+    if (wire && my_status == xplan::ST_OK && cm->expect_points && !(fault & 4u)) {
         room = soa_alloc(cm->expect_points);
         if (room) room_points = cm->expect_points;
     }
@@ -267,7 +290,7 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
         const size_t total = xplan::frame_total(W, all);
         uint32_t word = my_status;
         if (xplan::needs_buffer(cm->rank, W, all, loopback) && room_points < total) {
-            room = soa_alloc(total + total / 4 + 1024);
+            room = (fault & 2u) ? nullptr : soa_alloc(total + total / 4 + 1024);
             room_points = room ? total + total / 4 + 1024 : 0;
             if (!room) {
                 cwipc_log(CWIPC_LOG_LEVEL_ERROR, who, "out of device memory for the fused cloud: this rank sends its tile and gets no result");

@@ -520,10 +520,13 @@ __global__ void __launch_bounds__(BLOCK) affine_kernel(AffineArgs a, const float
         const double px = (double)x[i], py = (double)y[i], pz = (double)z[i];
         double rx, ry, rz;
         if (a.mode == 0) {
-            // three products summed in index order, then the translation: separately rounded f64 operations
-            rx = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[0], px), __dmul_rn(a.m[1], py)), __dmul_rn(a.m[2], pz)), a.m[3]);
-            ry = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[4], px), __dmul_rn(a.m[5], py)), __dmul_rn(a.m[6], pz)), a.m[7]);
-            rz = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.m[8], px), __dmul_rn(a.m[9], py)), __dmul_rn(a.m[10], pz)), a.m[11]);
+            // numpy's `rotmat @ xyz.T` is a dgemm whose inner loop is a chain of fused multiply-adds in index order: the first
+            // product rounded, the other two fused into the running sum; then the translation, a separate addition.  (Round 4:
+            // found with the outputs of the reference function itself, tests/golden/helper_vectors.npz -- three separately
+            // rounded products, the form of rounds 1-3, differ from it in the last bit for 3 of 3000 values of one matrix.)
+            rx = __dadd_rn(__fma_rn(a.m[2], pz, __fma_rn(a.m[1], py, __dmul_rn(a.m[0], px))), a.m[3]);
+            ry = __dadd_rn(__fma_rn(a.m[6], pz, __fma_rn(a.m[5], py, __dmul_rn(a.m[4], px))), a.m[7]);
+            rz = __dadd_rn(__fma_rn(a.m[10], pz, __fma_rn(a.m[9], py, __dmul_rn(a.m[8], px))), a.m[11]);
         } else {
             rx = __dmul_rn(__dadd_rn(px, a.m[3]), a.m[0]);
             ry = __dmul_rn(__dadd_rn(py, a.m[7]), a.m[0]);

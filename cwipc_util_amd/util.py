@@ -41,7 +41,7 @@ __all__ = [
     # MI355X extensions (no reference counterpart)
     'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked', 'cwipc_hip_device_planes',
     'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_from_device_slots', 'cwipc_hip_copy_device_aos',
-    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_hip_simulatecams', 'cwipc_hip_comm', 'cwipc_hip_comm_unique_id',
+    'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_downsample_pertile', 'cwipc_hip_simulatecams', 'cwipc_hip_comm', 'cwipc_hip_comm_unique_id',
 ]
 
 # reference util.py:86, 346, 348
@@ -968,6 +968,16 @@ def get_tiles_used(pc: cwipc_pointcloud_wrapper) -> List[int]:
     if rc < 0:
         raise CwipcError("get_tiles_used failed")
     return [t for t in range(256) if used[t]]
+
+
+def cwipc_downsample_pertile(pc: cwipc_pointcloud_wrapper, cellsize: float) -> cwipc_pointcloud_wrapper:
+    """Per-tile downsample, so points in different tiles are not combined (reference python/cwipc/registration/util.py:170-182):
+    for every tile number that occurs, ascending, tilefilter -> downsample; the results joined in that order.  The reference
+    folds pairwise joins; one n-ary join gives the same cloud (same order, ts = min, cellsize = min) in one pass."""
+    tiles_used = get_tiles_used(pc)
+    parts = [cwipc_downsample(cwipc_tilefilter(pc, tilenum), cellsize) for tilenum in tiles_used]
+    assert parts
+    return parts[0] if len(parts) == 1 else cwipc_join_multi(parts)
 
 
 def cwipc_hip_knn_mean_dist(pc: cwipc_pointcloud_wrapper, kNeighbors: int, stddevMulThresh: float = 1.0) -> Tuple[numpy.ndarray, float]:

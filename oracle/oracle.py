@@ -238,6 +238,30 @@ def offset_scale(pts: np.ndarray, x: float, y: float, z: float, scale: float) ->
     return out
 
 
+def tilefilter_masked(pts: np.ndarray, mask: int) -> np.ndarray:
+    """reference python/cwipc/registration/util.py:98-112 (cwipc_tilefilter_masked): points whose tile ANDed with the mask is
+    non-zero, in input order.  Pinned by tests/golden/helper_vectors.npz (outputs of the reference function itself)."""
+    pts = _pts(pts)
+    return pts[(pts['tile'] & np.uint8(mask & 0xff)) != 0].copy() if 0 <= mask <= 255 else pts[:0].copy()
+
+
+def downsample_pertile_plan(tiles_in_cloud, cellsize: float, calls: list):
+    """reference python/cwipc/registration/util.py:170-182 (cwipc_downsample_pertile), its calls only: for every tile number of
+    get_tiles_used (ascending) tilefilter -> downsample, results folded by pairwise joins, left to right.  Appends the calls to
+    `calls` in the form tests/golden/make_helper_vectors.py records them from the reference function; returns the fold's tag."""
+    result = None
+    for t in sorted(set(int(v) for v in tiles_in_cloud)):
+        calls.append(["tilefilter", t])
+        calls.append(["downsample", ["tile", t], float(cellsize)])
+        down = ["down", ["tile", t]]
+        if result is None:
+            result = down
+        else:
+            calls.append(["join", result, down])
+            result = ["join", result, down]
+    return result
+
+
 def tiles_used(pts: np.ndarray):
     """reference python/cwipc/registration/util.py:285-293 (get_tiles_used)."""
     return sorted(np.unique(_pts(pts)['tile']).tolist())

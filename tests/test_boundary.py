@@ -354,6 +354,32 @@ def test_product_does_not_import_the_oracle():
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
 
 
+def test_shipped_library_holds_no_test_infrastructure():
+    """The multi-rank exchange tests run a build of the library with an in-process stand-in for RCCL and fault hooks
+    (tests/standin/).  The shipped library must hold neither: its RCCL entry points are undefined symbols that librccl serves,
+    and the hooks' environment variable does not occur in it; the stand-in build is the other way round."""
+    import subprocess
+    shipped = os.path.join(ROOT, "cwipc_util_amd", "lib", "libcwipc_util.so")
+    blob = open(shipped, "rb").read()
+    assert b"CWIPC_TEST_EXCHANGE_FAULTS" not in blob and b"rccl stand-in" not in blob
+    dyn = subprocess.run(["nm", "-D", shipped], capture_output=True, text=True, check=True).stdout
+    for name in ("ncclAllGather", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclCommInitRank", "ncclCommDestroy", "ncclGetUniqueId"):
+        assert any(line.split()[-2:] == ["U", name] for line in dyn.splitlines()), name
+    standin = os.path.join(ROOT, "tests", "standin", "lib", "libcwipc_util.so")
+    if os.path.exists(standin):   # (built by __graft_entry__.build(); test infrastructure)
+        blob = open(standin, "rb").read()
+        assert b"CWIPC_TEST_EXCHANGE_FAULTS" in blob and b"rccl stand-in" in blob
+        dyn = subprocess.run(["nm", "-D", standin], capture_output=True, text=True, check=True).stdout
+        assert "nccl" not in dyn
+    # and nothing of the product names the stand-in
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "cwipc_util_amd")):
+        if os.path.basename(dirpath) in ("build", "build_dbg", "lib", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".inc")):
+                assert "rccl_standin" not in open(os.path.join(dirpath, f)).read(), f
+
+
 def test_capturer_registry(cwipc):
     """Camera plugins register a factory (reference src/cwipc_capturer.cpp:152-160); cwipc_capturer dispatches on
     the "type" of the configuration.  A plugin stand-in that hands out the synthetic source."""

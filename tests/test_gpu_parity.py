@@ -214,12 +214,9 @@ def test_transform_matrix(gpu, oracle, synth):
     got, exp = out.get_numpy_array(), oracle.transform(pts, m)
     assert out.timestamp() == 77 and out.cellsize() == pc.cellsize()
     assert same(got[['r', 'g', 'b', 'tile']], exp[['r', 'g', 'b', 'tile']])
-    # float64 sums of three products: numpy's matmul may contract them differently from the three separately
-    # rounded products here, which can flip the final rounding to fp32 for a handful of values
+    # bit for bit: the kernel rounds where numpy's matrix product rounds (a chain of fused multiply-adds in index order)
     for f in ('x', 'y', 'z'):
-        d = np.abs(got[f].astype(np.float64) - exp[f].astype(np.float64))
-        assert (d <= np.spacing(np.abs(exp[f]))).all(), f
-        assert (d != 0).mean() < 1e-4, f
+        assert (got[f] == exp[f]).all(), (f, int((got[f] != exp[f]).sum()))
     # the identity leaves the cloud as it is (but for the sign of zeros: -0 + 0 = +0, in numpy as here)
     assert same(gpu.cwipc_transform(pc, np.eye(4)).get_numpy_array(), oracle.transform(pts, np.eye(4)))
 
@@ -234,6 +231,128 @@ def test_transform_filter_offset_scale(gpu, oracle, synth):
     assert out.timestamp() == 5
     assert out.cellsize() == pytest.approx(np.float32(np.float64(np.float32(cs)) * 1.7), rel=0, abs=0)
     assert same(gpu.cwipc_offset_scale(make_cloud(gpu, pts[:0], cs), 1, 2, 3, 4).get_numpy_array(), pts[:0])
+
+
+# ---------------------------------------------------------------------------
+# outputs of the reference's own Python (tests/golden/helper_vectors.npz, made by tests/golden/make_helper_vectors.py from the
+# function bodies under /root/reference in the build container): the GPU paths must reproduce them, the oracle is not in the loop
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def helper_vectors():
+    import json
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "helper_vectors.npz"))
+    return d, json.loads(bytes(d["meta_json"]).decode())
+
+
+def test_reference_vectors_masked_tilefilter_and_tiles_used(gpu, helper_vectors):
+    """cwipc_tilefilter_masked, get_tiles_used (reference python/cwipc/registration/util.py:98-112, 285-293)."""
+    d, _ = helper_vectors
+    for i in range(6):
+        pts = d["masked%d_in" % i]
+        pc = make_cloud(gpu, pts, 0.003 + 0.001 * i, 100 + i)
+        assert gpu.get_tiles_used(pc) == d["masked%d_tiles_used" % i].tolist()
+        for m in (0, 1, 2, 3, 4, 8, 15, 128, 255):
+            out = gpu.cwipc_tilefilter_masked(pc, m)
+            exp = d["masked%d_mask%d_out" % (i, m)]
+            assert same(out.get_numpy_array(), exp), (i, m)
+            ts, cs = d["masked%d_mask%d_meta" % (i, m)]
+            assert out.timestamp() == ts, (i, m)
+            if len(exp):   # (the reference's empty result is cwipc_from_points([], ts): its cellsize is 0; an empty cloud's cellsize says nothing)
+                assert out.cellsize() == cs, (i, m)
+
+
+def test_reference_vectors_transform(gpu, helper_vectors):
+    """cwipc_transform (reference python/cwipc/registration/util.py:295-309: numpy's float64 matrix product of the 3 x 3 block with
+    the float32 coordinates, plus the translation, stored as float32) -- bit for bit what the reference function returned."""
+    d, _ = helper_vectors
+    pts = d["transform_in"]
+    for name in ("identity", "rot_y_45", "translate", "general", "scale_shear"):
+        out = gpu.cwipc_transform(make_cloud(gpu, pts, 0.004, 7), d["transform_%s_matrix" % name])
+        got, exp = out.get_numpy_array(), d["transform_%s_out" % name]
+        assert same(got, exp), (name, int((got['x'] != exp['x']).sum()), int((got['y'] != exp['y']).sum()), int((got['z'] != exp['z']).sum()))
+        assert [out.timestamp(), out.cellsize()] == d["transform_%s_meta" % name].tolist()
+
+
+def test_reference_vectors_transform_filter(gpu, helper_vectors):
+    """TransformFilter (reference python/cwipc/filters/transform.py:32-49: a Python loop over the points, float64 arithmetic on
+    C floats): points, timestamp and cellsize as the reference filter returned them."""
+    from cwipc_util_amd.filters.transform import TransformFilter
+    d, _ = helper_vectors
+    pts = d["offsetscale_in"]
+    for i in range(4):
+        x, y, z, scale = d["offsetscale%d_params" % i]
+        out = TransformFilter(x, y, z, scale).filter(make_cloud(gpu, pts, 0.005, 9))
+        assert same(out.get_numpy_array(), d["offsetscale%d_out" % i]), i
+        assert [out.timestamp(), out.cellsize()] == d["offsetscale%d_meta" % i].tolist(), i
+
+
+def test_reference_vectors_downsample_pertile(gpu, oracle, helper_vectors):
+    """cwipc_downsample_pertile: the reference function's calls (recorded in the fixture: tiles ascending, tilefilter -> downsample
+    per tile, a left fold of joins) replayed with the oracle's filters give the cloud the product's one call must return."""
+    _, meta = helper_vectors
+    rng = np.random.default_rng(5)
+    for case in meta["pertile"]:
+        tiles = np.array(case["tiles_in_cloud"], dtype=np.uint8)
+        pts = oracle.empty(20000)
+        pts['x'], pts['y'], pts['z'] = rng.random(20000) * 0.5, rng.random(20000) * 0.5, rng.random(20000) * 0.5
+        pts['r'], pts['g'], pts['b'] = rng.integers(0, 256, 20000), rng.integers(0, 256, 20000), rng.integers(0, 256, 20000)
+        pts['tile'] = tiles[rng.integers(0, len(tiles), 20000)]
+        clouds = {}
+        for call in case["calls"]:      # the reference's calls, in its order
+            if call[0] == "tilefilter":
+                clouds[json_key(["tile", call[1]])] = oracle.tilefilter(pts, call[1])
+            elif call[0] == "downsample":
+                clouds[json_key(["down", call[1]])] = oracle.downsample(clouds[json_key(call[1])], 0.001, call[2])[0]
+            else:
+                clouds[json_key(["join", call[1], call[2]])] = oracle.join(clouds[json_key(call[1])], clouds[json_key(call[2])])
+        exp = clouds[json_key(case["result"])]
+        out = gpu.cwipc_downsample_pertile(make_cloud(gpu, pts, 0.001, 55), 0.0125)
+        got = out.get_numpy_array()
+        assert len(got) == len(exp) and out.timestamp() == 55
+        for f in ('r', 'g', 'b', 'tile'):
+            assert (got[f] == exp[f]).all(), f
+        for f in ('x', 'y', 'z'):
+            assert np.abs(got[f].astype(np.float64) - exp[f]).max() <= XYZ_TOL, f
+
+
+def json_key(obj):
+    import json
+    return json.dumps(obj)
+
+
+def test_reference_vectors_synchronizer_with_the_gpu_join(gpu, helper_vectors):
+    """The product's synchroniser with its real join (cwipc_join_multi on the device) on the scripts the reference's
+    `_Synchronizer.run` was driven with (reference python/cwipc/net/source_synchronizer.py:106-200): the same fused clouds --
+    which inputs, in which order, timestamp, cellsize -- and the same late / desync / missing statistics."""
+    from cwipc_util_amd.net.source_synchronizer import SyncCore
+    from oracle.synchronizer import ScriptedSource
+    _, meta = helper_vectors
+    for case in meta["synchronizer"][:16]:
+        sources = []
+        for t, rows in enumerate(case["script"]):
+            clouds = []
+            for k, (ts, cs, n, _gate) in enumerate(rows):
+                p = np.zeros(n, dtype=gpu.cwipc_point_numpy_dtype)
+                p['x'] = np.arange(n)
+                p['y'], p['z'], p['tile'] = t, k, 1 << t
+                clouds.append(make_cloud(gpu, p, cs, ts))
+            sources.append(ScriptedSource(clouds, [r[3] for r in rows]))
+        core = SyncCore(sources, prefer_partial_over_unsynced=case["prefer_partial_over_unsynced"])
+        produced = []
+        for _ in range(100000):
+            if any(s.eof() for s in core.sources):
+                break
+            r = core.poll()
+            if r is not None:
+                arr = r.get_numpy_array()
+                parts = []
+                for i in range(len(arr)):
+                    key = [int(arr['y'][i]), int(arr['z'][i])]
+                    if not parts or parts[-1] != key:
+                        parts.append(key)
+                produced.append({"timestamp": r.timestamp(), "cellsize": r.cellsize(), "count": r.count(), "parts": parts})
+        assert produced == case["produced"]
+        assert {"late": core.late_per_occurrence, "desync": core.desync_per_occurrence, "missing": core.missing_per_occurrence} == case["stats"]
 
 
 @pytest.mark.parametrize("npoints,angle", [(0, 0.0), (100000, 0.7), (1000000, 2.5), (300000, 1.6), (10000000, 0.0)])
