@@ -301,8 +301,11 @@ def bench_config5(cwipc, rank: int, world: int, frames: int, warmup: int, fence,
         lat.append(time.perf_counter() - t0)
     fence()
     elapsed = time.perf_counter() - t_all
-    # what PCIe adds: host arrays in, host array out (rank-local part of the chain only)
-    host_ms = None
+    # what PCIe adds: host arrays in, host array out (rank-local part of the chain only).  Two ways: ordinary numpy arrays through
+    # cwipc_from_numpy_array on the calling thread and get_numpy_array() at the end (what a caller of the reference does), and
+    # (r4) arrays in page-locked memory (cwipc_hip_pinned_points), every tile's cloud made by the thread that filters it -- so
+    # that tile t's upload runs while tile t - 1 computes -- and the fused cloud written into a page-locked array (copy_into)
+    host_ms = host_pinned_ms = upload_gbps = None
     if tiles and world == 1:
         arrays = [(pc.get_numpy_array().copy(), pc.cellsize(), pc.timestamp()) for pc in tiles]
         times = []
@@ -318,11 +321,40 @@ def bench_config5(cwipc, rank: int, world: int, frames: int, warmup: int, fence,
             if i >= 3:
                 times.append(time.perf_counter() - t0)
         host_ms = float(np.median(times)) * 1e3
+        pinned = []
+        for a, cs, ts in arrays:
+            p = cwipc.cwipc_hip_pinned_points(len(a))
+            p[:] = a
+            pinned.append((p, cs, ts))
+        out_buf = cwipc.cwipc_hip_pinned_points(sum(len(a) for a, _, _ in arrays))
+
+        def chain_from_host(item):
+            a, cs, ts = item
+            pc = cwipc.cwipc_from_numpy_array(a, ts)
+            pc._set_cellsize(cs)
+            return chain(pc)
+
+        times, up = [], []
+        for i in range(20 + 3):
+            t0 = time.perf_counter()
+            outs = list(pool.map(chain_from_host, pinned)) if pool is not None else [chain_from_host(it) for it in pinned]
+            f = cwipc.cwipc_join_multi(outs)
+            f.copy_into(out_buf[:f.count()])
+            if i >= 3:
+                times.append(time.perf_counter() - t0)
+        host_pinned_ms = float(np.median(times)) * 1e3
+        for i in range(10):   # the upload alone: eight tiles from page-locked arrays, one after the other on this thread
+            t0 = time.perf_counter()
+            keep = [cwipc.cwipc_from_numpy_array(a, ts) for a, _, ts in pinned]
+            up.append(time.perf_counter() - t0)
+            del keep
+        upload_gbps = sum(a.nbytes for a, _, _ in pinned) / float(np.median(up)) / 1e9
     if pool is not None:
         pool.shutdown()
     lat_ms = np.array(lat) * 1e3
     return {"elapsed": elapsed, "n_tile": n_tile, "fused_points": fused_points, "tiles_here": len(mine), "threads": nthreads,
-            "p50_ms": float(np.percentile(lat_ms, 50)), "p99_ms": float(np.percentile(lat_ms, 99)), "host_io_ms_per_frame": host_ms}
+            "p50_ms": float(np.percentile(lat_ms, 50)), "p99_ms": float(np.percentile(lat_ms, 99)), "host_io_ms_per_frame": host_ms,
+            "host_pinned_io_ms_per_frame": host_pinned_ms, "pinned_upload_gbps": upload_gbps}
 
 
 def bench_config3(cwipc, pc, n: int, runs: int = 5):
@@ -654,6 +686,8 @@ def main() -> None:
             "inputs_resident_in_hbm": True, "tile_threads_per_rank": c5["threads"],
             "frames_overlapped": False,
             "host_arrays_in_and_out_ms_per_frame": c5["host_io_ms_per_frame"],
+            "page_locked_arrays_in_and_out_ms_per_frame": c5["host_pinned_io_ms_per_frame"],
+            "page_locked_upload_GBps": c5["pinned_upload_gbps"],
             "h2d_d2h_share_of_that": (1.0 - ms_frame / c5["host_io_ms_per_frame"]) if c5["host_io_ms_per_frame"] else None,
         }
     config3 = None

@@ -7,7 +7,11 @@
 // the pool and the profile table are the only shared state and are locked.
 #include "internal.hpp"
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -175,23 +179,135 @@ void host_free(void *ptr, bool pinned) {
     if (!keep) (void)hipHostFree(ptr);
 }
 
-void parallel_memcpy(void *dst, const void *src, size_t bytes) {
-    const size_t piece = (size_t)8 << 20;
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nthreads = bytes / piece;
-    if (nthreads > 4) nthreads = 4;
-    if (hw && nthreads > hw) nthreads = hw;
-    if (nthreads < 2) { memcpy(dst, src, bytes); return; }
-    const size_t per = ((bytes / nthreads) + 4095) & ~(size_t)4095;
+// A few threads that live as long as the process copy big buffers in pieces (round 4: a thread per piece and call, as in rounds
+// 1-3, cost more than a 5 MB camera tile's copy took; clouds of 1 MB and more now go in pieces of at least 256 KB).
+namespace {
+struct CopyPool {
+    struct Task { char *dst; const char *src; size_t len; };
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Task> tasks;
+    size_t pending = 0;
     std::vector<std::thread> workers;
-    for (size_t t = 1; t < nthreads; t++) {
-        const size_t off = t * per;
-        if (off >= bytes) break;
-        const size_t len = off + per < bytes ? per : bytes - off;
-        workers.emplace_back([=]() { memcpy((char *)dst + off, (const char *)src + off, len); });
+    explicit CopyPool(unsigned n) {
+        for (unsigned i = 0; i < n; i++)
+            workers.emplace_back([this]() {
+                for (;;) {
+                    Task t;
+                    {
+                        std::unique_lock<std::mutex> g(m);
+                        cv_work.wait(g, [&] { return !tasks.empty(); });
+                        t = tasks.front();
+                        tasks.pop_front();
+                    }
+                    memcpy(t.dst, t.src, t.len);
+                    {
+                        std::lock_guard<std::mutex> g(m);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+        for (auto &w : workers) w.detach();   // (they sleep on the queue; the process may end under them)
     }
-    memcpy(dst, src, per < bytes ? per : bytes);
-    for (auto &w : workers) w.join();
+};
+CopyPool *copy_pool() {
+    static CopyPool *pool = []() {
+        unsigned hw = std::thread::hardware_concurrency();
+        return new CopyPool(hw >= 8 ? 3u : hw >= 4 ? 2u : 1u);   // never destroyed: threads may outlive the statics
+    }();
+    return pool;
+}
+std::mutex g_copy_calls;   // one parallel copy at a time (the callers' own threads are the parallelism beyond that)
+}  // namespace
+
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t min_piece = (size_t)256 << 10;
+    if (bytes < ((size_t)1 << 20) || std::thread::hardware_concurrency() < 2 || !g_copy_calls.try_lock()) { memcpy(dst, src, bytes); return; }
+    std::lock_guard<std::mutex> one(g_copy_calls, std::adopt_lock);
+    CopyPool *pool = copy_pool();
+    const size_t parts = std::min<size_t>(pool->workers.size() + 1, bytes / min_piece);
+    const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
+    size_t queued = 0;
+    {
+        std::lock_guard<std::mutex> g(pool->m);
+        for (size_t off = per; off < bytes; off += per) {
+            pool->tasks.push_back({(char *)dst + off, (const char *)src + off, std::min(per, bytes - off)});
+            pool->pending++;
+            queued++;
+        }
+    }
+    if (queued) pool->cv_work.notify_all();
+    memcpy(dst, src, std::min(per, bytes));   // this thread takes the first piece
+    if (queued) {
+        std::unique_lock<std::mutex> g(pool->m);
+        pool->cv_done.wait(g, [&] { return pool->pending == 0; });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// page-locked buffers of the CALLER (round 4): memory from cwipc_hip_host_alloc, or the caller's own registered with
+// cwipc_hip_host_register.  cwipc_from_points on such a buffer reads it straight from the device (no staging copy on the host),
+// copy_uncompressed into one lets the DMA engine write it directly.
+// ---------------------------------------------------------------------------
+namespace {
+std::mutex g_user_pinned_mutex;
+struct UserPinned { size_t bytes; bool ours; uintptr_t dev_base; };   // ours: to free with hipHostFree / else registered by the caller; dev_base: the device's address of the first byte
+std::map<uintptr_t, UserPinned> g_user_pinned;   // by start address
+}  // namespace
+
+void *host_range_device_alias(const void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return nullptr;
+    std::lock_guard<std::mutex> lock(g_user_pinned_mutex);
+    if (g_user_pinned.empty()) return nullptr;
+    auto it = g_user_pinned.upper_bound((uintptr_t)ptr);
+    if (it == g_user_pinned.begin()) return nullptr;
+    --it;
+    if ((uintptr_t)ptr < it->first || (uintptr_t)ptr + bytes > it->first + it->second.bytes) return nullptr;
+    return (void *)(it->second.dev_base + ((uintptr_t)ptr - it->first));
+}
+
+extern "C" void *cwipc_hip_host_alloc(size_t bytes) {
+    if (!bytes || device_count() < 1) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) { (void)hipGetLastError(); d = p; }
+    std::lock_guard<std::mutex> lock(g_user_pinned_mutex);
+    g_user_pinned[(uintptr_t)p] = UserPinned{bytes, true, (uintptr_t)d};
+    return p;
+}
+
+extern "C" void cwipc_hip_host_free(void *ptr) {
+    if (!ptr) return;
+    {
+        std::lock_guard<std::mutex> lock(g_user_pinned_mutex);
+        auto it = g_user_pinned.find((uintptr_t)ptr);
+        if (it == g_user_pinned.end() || !it->second.ours) return;
+        g_user_pinned.erase(it);
+    }
+    (void)hipHostFree(ptr);
+}
+
+extern "C" int cwipc_hip_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes || device_count() < 1) return -1;
+    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, ptr, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostUnregister(ptr); return -1; }
+    std::lock_guard<std::mutex> lock(g_user_pinned_mutex);
+    g_user_pinned[(uintptr_t)ptr] = UserPinned{bytes, false, (uintptr_t)d};
+    return 0;
+}
+
+extern "C" int cwipc_hip_host_unregister(void *ptr) {
+    if (!ptr) return -1;
+    {
+        std::lock_guard<std::mutex> lock(g_user_pinned_mutex);
+        auto it = g_user_pinned.find((uintptr_t)ptr);
+        if (it == g_user_pinned.end() || it->second.ours) return -1;
+        g_user_pinned.erase(it);
+    }
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return 0;
 }
 
 void pool_free(void *ptr) {

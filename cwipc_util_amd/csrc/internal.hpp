@@ -227,8 +227,11 @@ struct DeferredResult {
 // read and write it directly, no staging copy), plain malloc otherwise.
 void *host_alloc(size_t bytes, bool *pinned);
 void host_free(void *ptr, bool pinned);
-// memcpy split over a few threads for buffers of many megabytes (one core copies at ~10 GB/s)
+// memcpy split over a few threads for buffers of a megabyte and more (one core copies at 10-20 GB/s)
 void parallel_memcpy(void *dst, const void *src, size_t bytes);
+// [ptr, ptr + bytes) in page-locked memory the CALLER holds (cwipc_hip_host_alloc / cwipc_hip_host_register): the address a kernel
+// reaches it under; nullptr for any other memory
+void *host_range_device_alias(const void *ptr, size_t bytes);
 
 // Host representation: AoS exactly as handed in through the C-ABI.
 struct HostAoS {

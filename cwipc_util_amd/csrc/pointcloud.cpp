@@ -226,6 +226,16 @@ int cwipc_hip_pointcloud::copy_impl(struct cwipc_point *pointbuf, size_t size, b
     if (!dev || !device_available("copy_uncompressed")) return -1;
     ThreadCtx &c = tctx();
     if (!c.ensure()) return -1;
+    // r4: a destination in page-locked memory of the caller is written by the interleave kernel itself, over PCIe
+    if (void *alias = dst_pinned ? nullptr : host_range_device_alias(pointbuf, need)) {
+        dev->wait_on(c.stream);
+        k::soa_to_aos(*dev, (cwipc_point *)alias, m_npoints, c.stream);
+        if (!c.sync()) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "copy_uncompressed: device to host copy failed");
+            return -1;
+        }
+        return (int)m_npoints;
+    }
     void *aos = pool_alloc(need);
     if (!aos) return -1;
     dev->wait_on(c.stream);
@@ -283,19 +293,41 @@ int cwipc_hip_pointcloud::from_points(const cwipc_point *points, size_t size, in
         cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "from_points: size and npoint inconsistent");
         return -1;
     }
-    auto host = std::make_shared<HostAoS>();
-    host->npoints = (size_t)npoint;
-    host->points = (cwipc_point *)host_alloc(size, &host->pinned);
-    if (!host->points) {
-        cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "from_points: could not allocate memory for points, size=" + std::to_string(size));
-        return -1;
+    // r4: a buffer in page-locked memory the caller holds (cwipc_hip_host_alloc / cwipc_hip_host_register) is read by the
+    // de-interleave kernel where it lies, over PCIe: the owned copy is the SoA planes in HBM, there is no copy on the host (one is
+    // made from the device if somebody asks for host bytes).  The kernel is done when the call returns: the buffer is the caller's again.
+    std::shared_ptr<DeviceSoA> dev;
+    const cwipc_point *alias = size >= ((size_t)1 << 16) ? (const cwipc_point *)host_range_device_alias(points, size) : nullptr;
+    if (alias && cwipc_hip_device_count() > 0 && current_device() < cwipc_hip_device_count()) {
+        ThreadCtx &c = tctx();
+        if (c.ensure()) {
+            dev = soa_alloc((size_t)npoint);
+            if (dev) {
+                k::aos_to_soa(alias, *dev, (size_t)npoint, c.stream);
+                if (!c.sync()) { (void)hipGetLastError(); dev.reset(); }
+            }
+            if (dev) {
+                dev->first[0] = points[0].x; dev->first[1] = points[0].y; dev->first[2] = points[0].z;
+                dev->has_first = true;
+            }
+        }
     }
-    if (size) parallel_memcpy(host->points, points, size);
+    std::shared_ptr<HostAoS> host;
+    if (!dev) {
+        host = std::make_shared<HostAoS>();
+        host->npoints = (size_t)npoint;
+        host->points = (cwipc_point *)host_alloc(size, &host->pinned);
+        if (!host->points) {
+            cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_util", "from_points: could not allocate memory for points, size=" + std::to_string(size));
+            return -1;
+        }
+        if (size) parallel_memcpy(host->points, points, size);
+    }
     std::lock_guard<std::mutex> lock(m_lock);
     m_timestamp = timestamp;
     m_npoints = (size_t)npoint;
     m_host = host;
-    m_dev.reset();
+    m_dev = dev;
     m_exact_size = exact_size;   // (the reference's from_points clouds insist on their exact size in copy_uncompressed, its PCL-backed ones take any buffer that is large enough)
     if (!m_has_data) {
         m_has_data = true;

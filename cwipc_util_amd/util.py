@@ -39,7 +39,7 @@ __all__ = [
     'cwipc_downsample', 'cwipc_remove_outliers', 'cwipc_tilefilter', 'cwipc_tilemap', 'cwipc_colormap',
     'cwipc_join', 'cwipc_join_multi', 'cwipc_crop',
     # MI355X extensions (no reference counterpart)
-    'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked', 'cwipc_hip_device_planes',
+    'cwipc_hip_device_count', 'cwipc_hip_set_device', 'cwipc_hip_upload', 'cwipc_hip_pinned_points', 'cwipc_hip_pin_array', 'cwipc_hip_colorize', 'cwipc_tilefilter_masked', 'cwipc_hip_device_planes',
     'cwipc_hip_profile', 'cwipc_hip_knn_mean_dist', 'cwipc_hip_from_device_aos', 'cwipc_hip_from_device_slots', 'cwipc_hip_copy_device_aos',
     'cwipc_transform', 'cwipc_offset_scale', 'get_tiles_used', 'cwipc_downsample_pertile', 'cwipc_hip_simulatecams', 'cwipc_hip_comm', 'cwipc_hip_comm_unique_id',
 ]
@@ -196,6 +196,10 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_synchronize': ([], None),
     'cwipc_hip_pool_bytes': ([], _c.c_size_t),
     'cwipc_hip_pool_trim': ([], None),
+    'cwipc_hip_host_alloc': ([_c.c_size_t], _c.c_void_p),
+    'cwipc_hip_host_free': ([_c.c_void_p], None),
+    'cwipc_hip_host_register': ([_c.c_void_p, _c.c_size_t], _c.c_int),
+    'cwipc_hip_host_unregister': ([_c.c_void_p], _c.c_int),
     'cwipc_hip_upload': ([cwipc_pointcloud_p], _c.c_int),
     'cwipc_hip_drop_host_copy': ([cwipc_pointcloud_p], _c.c_int),
     'cwipc_hip_is_device_resident': ([cwipc_pointcloud_p], _c.c_int),
@@ -399,6 +403,18 @@ class cwipc_pointcloud_wrapper(cwipc_pointcloud_abstract):
             raise CwipcError("cwipc_pointcloud_copy_uncompressed failed")
         self._points = cwipc_point_array(count=nPoints, values=buffer)
         self._bytes = buffer
+
+    def copy_into(self, np_points: numpy.ndarray) -> int:
+        """The points into a caller's contiguous numpy array of the cwipc_point dtype with exactly count() elements (the C call
+        cwipc_pointcloud_copy_uncompressed, reference src/cwipc_util.cpp:226-250, without the bytearray get_points() makes): an
+        array in page-locked memory (cwipc_hip_pinned_points, cwipc_hip_pin_array) is written by the GPU directly."""
+        assert self._cwipc
+        if not np_points.flags['C_CONTIGUOUS'] or np_points.dtype.itemsize != 16:
+            raise ValueError("copy_into: a contiguous array of 16-byte cwipc_point records is needed")
+        n = cwipc_util_dll_load().cwipc_pointcloud_copy_uncompressed(self.as_cwipc_p(), ctypes.cast(np_points.ctypes.data, _BYTES), np_points.nbytes)
+        if n < 0:
+            raise CwipcError("cwipc_pointcloud_copy_uncompressed failed")
+        return n
 
     def get_packet(self) -> bytearray:
         assert self._cwipc
@@ -853,6 +869,51 @@ def cwipc_hip_device_count() -> int:
 def cwipc_hip_set_device(device: int) -> None:
     if cwipc_util_dll_load().cwipc_hip_set_device(device) != 0:
         raise CwipcError(f"cwipc_hip_set_device({device}) failed")
+
+
+def cwipc_hip_pinned_points(npoints: int) -> cwipc_point_numpy_array_value_type:
+    """A structured numpy array (cwipc_point dtype) of npoints records in page-locked memory (include/cwipc_util_amd/hip_ext.h,
+    cwipc_hip_host_alloc): cwipc_from_numpy_array on it -- or on a slice of it -- is read by the GPU where it lies, without the
+    copy into a staging buffer that ordinary host memory needs; copy_into() of a cloud writes it directly.  For buffers that are
+    reused frame after frame (a capturer's output, a decoder's).  The memory is released with the array."""
+    import weakref
+    dll = cwipc_util_dll_load()
+    nbytes = max(int(npoints), 1) * 16
+    ptr = dll.cwipc_hip_host_alloc(nbytes)
+    if not ptr:
+        raise CwipcError("cwipc_hip_host_alloc failed (no GPU, or no page-locked memory left)")
+    buf = (ctypes.c_byte * nbytes).from_address(ptr)
+    arr = numpy.frombuffer(buf, dtype=cwipc_point_numpy_dtype, count=int(npoints))
+    weakref.finalize(buf, dll.cwipc_hip_host_free, ptr)   # (arr.base keeps buf alive)
+    return arr
+
+
+class cwipc_hip_pin_array:
+    """Page-lock the memory of an existing contiguous numpy array for as long as this object lives (cwipc_hip_host_register): the
+    array can then be handed to cwipc_from_numpy_array / filled by copy_into() without a staging copy.  Use as a context manager or
+    keep the object; registering costs about as much as copying the array a few times, so it pays for arrays that are reused."""
+
+    def __init__(self, array: numpy.ndarray):
+        if not array.flags['C_CONTIGUOUS']:
+            raise ValueError("cwipc_hip_pin_array: the array must be contiguous")
+        self._array = array
+        self._ptr = array.ctypes.data
+        if cwipc_util_dll_load().cwipc_hip_host_register(self._ptr, array.nbytes) != 0:
+            self._ptr = None
+            raise CwipcError("cwipc_hip_host_register failed")
+
+    def release(self) -> None:
+        if self._ptr:
+            cwipc_util_dll_load().cwipc_hip_host_unregister(self._ptr)
+            self._ptr = None
+
+    def __enter__(self): return self._array
+    def __exit__(self, *exc): self.release()
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def cwipc_hip_upload(pc: cwipc_pointcloud_wrapper, drop_host_copy: bool = False) -> None:

@@ -27,6 +27,18 @@ _CWIPC_UTIL_EXPORT size_t cwipc_hip_pool_bytes(void);         /* bytes currently
 _CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_bytes(void);    /* device bytes held by the voxel filter's workspaces (leaf grids; two per thread that downsamples) */
 _CWIPC_UTIL_EXPORT void cwipc_hip_pool_trim(void);            /* return cached device memory to the driver */
 
+/* ---- page-locked host buffers of the caller (round 4) ----
+ * The copy path of the reference (src/cwipc_util.cpp:329-354 from_points, :226-250 copy_uncompressed) moves bytes between the
+ * caller's buffer and a buffer the cloud owns.  Here the owned copy lives in HBM, and a buffer the DMA engines cannot reach costs
+ * one more copy on the host on the way.  A caller that keeps its point buffers in page-locked memory -- allocated here, or its own
+ * memory registered once (a numpy array that is reused frame after frame) -- skips it: cwipc_from_points / cwipc_from_packet read
+ * such a buffer straight from the device (and have finished reading when they return, as the reference's copy has),
+ * cwipc_pointcloud_copy_uncompressed / copy_packet into one are written by the DMA engine directly.  Nothing else changes. */
+_CWIPC_UTIL_EXPORT void *cwipc_hip_host_alloc(size_t bytes);                 /* NULL without a GPU or memory */
+_CWIPC_UTIL_EXPORT void cwipc_hip_host_free(void *ptr);
+_CWIPC_UTIL_EXPORT int cwipc_hip_host_register(void *ptr, size_t bytes);     /* 0 ok; the memory stays the caller's */
+_CWIPC_UTIL_EXPORT int cwipc_hip_host_unregister(void *ptr);
+
 /* ---- residency ----
  * A cloud made by cwipc_from_points lives in host memory until a filter needs
  * it; filter results live in HBM (SoA planes x,y,z:f32[n], rgbt:u32[n] with

@@ -38,6 +38,47 @@ def test_upload_download_roundtrip(gpu, oracle, synth, npoints):
     assert same(gpu.cwipc_from_packet(pkt).get_numpy_array(), pts)
 
 
+def test_page_locked_buffers_of_the_caller(gpu, oracle, synth):
+    """Round 4, the copy path with buffers the DMA engines can reach (include/cwipc_util_amd/hip_ext.h: cwipc_hip_host_alloc /
+    cwipc_hip_host_register): cwipc_from_points reads such a buffer from the device where it lies and has finished with it when it
+    returns (the reference's from_points owns a copy at that point, src/cwipc_util.cpp:329-354), copy_uncompressed writes it from
+    the device (:226-250).  Same bytes as through ordinary memory, whatever the offset inside the allocation."""
+    pts, cs = synth(300000, 0.4)
+    n = len(pts)
+    pinned = gpu.cwipc_hip_pinned_points(n + 1000)
+    pinned[37:37 + n] = pts                                     # a buffer that starts somewhere inside the allocation
+    pc = gpu.cwipc_from_numpy_array(pinned[37:37 + n], 5)
+    pc._set_cellsize(cs)
+    pinned[:] = np.zeros(1, dtype=pinned.dtype)[0]              # the caller reuses its buffer right away
+    assert same(pc.get_numpy_array(), pts)                      # (the host copy is made from the device now)
+    out = gpu.cwipc_tilefilter(pc, 1)
+    exp = oracle.tilefilter(pts, 1)
+    dst = gpu.cwipc_hip_pinned_points(len(exp))
+    assert out.copy_into(dst) == len(exp) and same(dst, exp)
+    plain = np.zeros(len(exp), dtype=dst.dtype)
+    assert out.copy_into(plain) == len(exp) and same(plain, exp)
+    with pytest.raises(gpu.CwipcError):
+        out.copy_into(np.zeros(len(exp) - 1, dtype=dst.dtype))  # the reference's size check (:231) stays
+    # the caller's own array, registered
+    own = pts.copy()
+    with gpu.cwipc_hip_pin_array(own) as arr:
+        pc2 = gpu.cwipc_from_numpy_array(arr, 6)
+        pc2._set_cellsize(cs)
+        got, _ = gpu.cwipc_downsample(pc2, 0.01).get_numpy_array(), None
+        back = np.zeros_like(own)
+        with gpu.cwipc_hip_pin_array(back) as b:
+            assert pc2.copy_into(b) == n
+        assert same(back, pts)
+    e, _ = oracle.downsample(pts, cs, 0.01)
+    assert len(got) == len(e) and (got['tile'] == e['tile']).all()
+    # small clouds and empty ones take the ordinary way
+    small = gpu.cwipc_hip_pinned_points(100)
+    small[:] = pts[:100]
+    assert same(gpu.cwipc_from_numpy_array(small, 1).get_numpy_array(), pts[:100])
+    assert gpu.cwipc_from_numpy_array(small[:0], 1).count() == 0
+
+
+
 # ---------------------------------------------------------------------------
 # exact filters
 # ---------------------------------------------------------------------------
