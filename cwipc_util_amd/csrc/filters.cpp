@@ -71,11 +71,13 @@ std::shared_ptr<DeviceSoA> compact(const DeviceSoA &src, const k::Predicate &p, 
     const uint32_t tag = ++c.tag ? c.tag : ++c.tag;
     volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(c.host_words);
     *word = 0ull;
-    if (!k::compact_count_scan(src, p, counts, c.tickets, reinterpret_cast<unsigned long long *>(c.host_words), tag, c.stream)) {
+    if (k::compact_count_scan(src, p, counts, c.tickets, reinterpret_cast<unsigned long long *>(c.host_words), tag, c.stream)) {
+        k::compact_scatter(src, p, counts, *dst, c.stream);
+    } else {
+        // big clouds (r4): two launches, not three -- the scatter kernel's workgroups add up the counts in front of them themselves
         k::compact_count(src, p, counts, c.stream);
-        k::compact_scan(counts, nb, reinterpret_cast<unsigned long long *>(c.host_words), tag, c.stream);
+        k::compact_scatter(src, p, counts, *dst, c.stream, reinterpret_cast<unsigned long long *>(c.host_words), tag);
     }
-    k::compact_scatter(src, p, counts, *dst, c.stream);
     bool ok = hipGetLastError() == hipSuccess;
     // The count is there when the scan kernel is done; the scatter kernel behind it needs no more attention
     // from the host, so a caller that allows it gets the result back with that kernel still running.

@@ -342,7 +342,9 @@ bool compact_count_scan(const DeviceSoA &src, const Predicate &p, uint32_t *bloc
 // Exclusive scan of block_counts in place; total written to *total_dev.
 void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *total_host, uint32_t tag, hipStream_t s);
 // Pass 2: scatter kept points to dst in input order.
-void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s);
+// total_host != nullptr: block_offsets are the count kernel's COUNTS; every workgroup sums those in front of it, the first one publishes the total
+void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s,
+                     unsigned long long *total_host = nullptr, uint32_t tag = 0);
 
 // Per-point maps on the rgbt word (x,y,z copied).
 void map_tile(const DeviceSoA &src, const DeviceSoA &dst, const uint8_t *dev_map256, hipStream_t s);

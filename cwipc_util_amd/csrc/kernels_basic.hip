@@ -132,13 +132,13 @@ __device__ __forceinline__ bool keep_point(const PredArgs &p, float x, float y, 
 }
 
 // Loads ITEMS consecutive points of one lane; out-of-range items report keep = false.
-template <bool NEED_XYZ>
+template <bool NEED_XYZ, bool NEED_W = true>
 __device__ __forceinline__ unsigned lane_mask(const PredArgs &p, const float *__restrict__ x, const float *__restrict__ y,
                                               const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t base, size_t n,
                                               float4 &vx, float4 &vy, float4 &vz, uint4 &vw) {
     unsigned m = 0;
     if (base + ITEMS <= n) {
-        vw = *(const uint4 *)(rgbt + base);
+        if (NEED_W) vw = *(const uint4 *)(rgbt + base);
         if (NEED_XYZ) {
             vx = *(const float4 *)(x + base);
             vy = *(const float4 *)(y + base);
@@ -153,7 +153,7 @@ __device__ __forceinline__ unsigned lane_mask(const PredArgs &p, const float *__
         uint32_t aw[4] = {0, 0, 0, 0};
         for (int j = 0; j < ITEMS; j++) {
             if (base + j < n) {
-                aw[j] = rgbt[base + j];
+                if (NEED_W) aw[j] = rgbt[base + j];
                 if (NEED_XYZ) { ax[j] = x[base + j]; ay[j] = y[base + j]; az[j] = z[base + j]; }
                 if (keep_point(p, ax[j], ay[j], az[j], aw[j], base + j)) m |= 1u << j;
             }
@@ -166,30 +166,66 @@ __device__ __forceinline__ unsigned lane_mask(const PredArgs &p, const float *__
     return m;
 }
 
+// The scatter kernel's loads (r4): the planes the predicate looks at first, the others only by lanes that keep a point -- a tile
+// filter that keeps half of a 10 M-point cloud does not read the coordinates of the other half (60 of 240 MB).
+__device__ __forceinline__ unsigned lane_mask_lazy(const PredArgs &p, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                   const uint32_t *__restrict__ rgbt, size_t base, size_t n, float4 &vx, float4 &vy, float4 &vz, uint4 &vw) {
+    if (base + ITEMS > n) return lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);   // (the ragged last lane, and lanes beyond the end)
+    unsigned m = 0;
+    if (p.mode == 1) {           // crop: the coordinates decide
+        vx = *(const float4 *)(x + base); vy = *(const float4 *)(y + base); vz = *(const float4 *)(z + base);
+        m |= keep_point(p, vx.x, vy.x, vz.x, 0u, base) ? 1u : 0u;
+        m |= keep_point(p, vx.y, vy.y, vz.y, 0u, base + 1) ? 2u : 0u;
+        m |= keep_point(p, vx.z, vy.z, vz.z, 0u, base + 2) ? 4u : 0u;
+        m |= keep_point(p, vx.w, vy.w, vz.w, 0u, base + 3) ? 8u : 0u;
+        if (m) vw = *(const uint4 *)(rgbt + base);
+    } else {                     // tile value, tile mask: the colour / tile word decides; outlier removal: d_i (no plane at all)
+        if (p.mode != 3) vw = *(const uint4 *)(rgbt + base);
+        m |= keep_point(p, 0.f, 0.f, 0.f, vw.x, base) ? 1u : 0u;
+        m |= keep_point(p, 0.f, 0.f, 0.f, vw.y, base + 1) ? 2u : 0u;
+        m |= keep_point(p, 0.f, 0.f, 0.f, vw.z, base + 2) ? 4u : 0u;
+        m |= keep_point(p, 0.f, 0.f, 0.f, vw.w, base + 3) ? 8u : 0u;
+        if (m) {
+            if (p.mode == 3) vw = *(const uint4 *)(rgbt + base);
+            vx = *(const float4 *)(x + base); vy = *(const float4 *)(y + base); vz = *(const float4 *)(z + base);
+        }
+    }
+    return m;
+}
+
+// kept points of one workgroup's tile (S steps of BLOCK * ITEMS points); the predicate's planes only
 template <int S>
-__global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
-                                                             const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
-                                                             uint32_t *__restrict__ block_counts) {
-    __shared__ uint32_t wave_sum[WAVES];
+__device__ __forceinline__ uint32_t count_tile(const PredArgs &p, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                               const uint32_t *__restrict__ rgbt, size_t n, uint32_t *wave_sum) {
     size_t tile0 = (size_t)blockIdx.x * (BLOCK * ITEMS * S);
     uint32_t cnt = 0;
     float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
-    uint4 vw;
+    uint4 vw = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < S; s++) {
         size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
-        unsigned m = (p.mode == 1) ? lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
-                                   : lane_mask<false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
+        // (crop looks at the coordinates only, outlier removal at d_i only, the tile predicates at the colour / tile word only)
+        unsigned m = (p.mode == 1) ? lane_mask<true, false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
+                   : (p.mode == 3) ? lane_mask<false, false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
+                                   : lane_mask<false, true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
         cnt += __popc(m);
     }
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
     if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
+    uint32_t t = 0;
+    if (threadIdx.x == 0)
         for (int w = 0; w < WAVES; w++) t += wave_sum[w];
-        block_counts[blockIdx.x] = t;
-    }
+    return t;   // (thread 0's value is the tile's count)
+}
+
+template <int S>
+__global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
+                                                             uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t wave_sum[WAVES];
+    const uint32_t t = count_tile<S>(p, x, y, z, rgbt, n, wave_sum);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = t;
 }
 
 // The exclusive scan of the block counts by the workgroup that runs it (NT lanes): counts[i] <- sum of those before, counts[nblocks]
@@ -236,23 +272,8 @@ __global__ void __launch_bounds__(BLOCK) compact_count_scan_kernel(PredArgs p, c
                                                                   unsigned long long *__restrict__ total, uint32_t tag) {
     __shared__ uint32_t wave_sum[WAVES];
     __shared__ uint32_t is_last;
-    size_t tile0 = (size_t)blockIdx.x * (BLOCK * ITEMS * S);
-    uint32_t cnt = 0;
-    float4 vx = make_float4(0, 0, 0, 0), vy = vx, vz = vx;
-    uint4 vw;
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
-        unsigned m = (p.mode == 1) ? lane_mask<true>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw)
-                                   : lane_mask<false>(p, x, y, z, rgbt, base, n, vx, vy, vz, vw);
-        cnt += __popc(m);
-    }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
-    __syncthreads();
+    const uint32_t t = count_tile<S>(p, x, y, z, rgbt, n, wave_sum);
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < WAVES; w++) t += wave_sum[w];
         __hip_atomic_store(&block_counts[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t before = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         is_last = before == gridDim.x - 1 ? 1u : 0u;
@@ -273,18 +294,43 @@ __global__ void __launch_bounds__(1024) compact_scan_kernel(uint32_t *__restrict
     scan_block_counts<1024>(counts, nblocks, total, tag);
 }
 
-template <int S>
+// SUMS: the workgroup adds the counts of the workgroups in front of it up itself (big clouds, r4: the one-workgroup scan kernel between the
+// count and the scatter kernel and its two kernel boundaries go; a workgroup reads 1200 counts on average, next to a tile of 64 KB), and
+// workgroup 0 leaves the total for the host.  Otherwise block_offsets are offsets already (small clouds: scanned by the count kernel's last
+// workgroup), the total behind them.
+template <int S, bool SUMS>
 __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
                                                                const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
                                                                const uint32_t *__restrict__ block_offsets, float *__restrict__ ox,
-                                                               float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
+                                                               float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow,
+                                                               unsigned long long *__restrict__ total_host, uint32_t tag) {
     __shared__ uint32_t wave_sum[S][WAVES];
+    __shared__ uint32_t prefix_sum[2][WAVES];
+    __shared__ uint32_t stage[WAVES][4][64 * ITEMS];   // per wave: the kept points of one step in output order, plane by plane
+    uint32_t before_me = 0, everything = 0;
+    if (SUMS) {
+        uint32_t lo = 0, all = 0;
+        for (uint32_t i = threadIdx.x; i < gridDim.x; i += BLOCK) {
+            const uint32_t v = block_offsets[i];
+            all += v;
+            if (i < blockIdx.x) lo += v;
+        }
+        for (int off = 32; off > 0; off >>= 1) { lo += __shfl_down(lo, off, 64); all += __shfl_down(all, off, 64); }
+        if ((threadIdx.x & 63) == 0) { prefix_sum[0][threadIdx.x >> 6] = lo; prefix_sum[1][threadIdx.x >> 6] = all; }
+        __syncthreads();
+        for (int w = 0; w < WAVES; w++) { before_me += prefix_sum[0][w]; everything += prefix_sum[1][w]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store(total_host, ((unsigned long long)tag << 32) | everything, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        before_me = block_offsets[blockIdx.x];
+        everything = block_offsets[gridDim.x];
+    }
     // every point kept (a tile filter on a cloud of that one tile, a crop box around everything): the host hands the input's
     // planes on as the result, nothing is copied
-    if (block_offsets[gridDim.x] == n) return;
+    if (everything == n) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile0 = (size_t)blockIdx.x * (BLOCK * ITEMS * S);
-    const size_t out0 = block_offsets[blockIdx.x];
+    const size_t out0 = before_me;
     // the whole tile is loaded before anything else happens (16 loads of 16 B per lane in flight);
     // the scatter needs all four planes of the kept points
     float4 vx[S], vy[S], vz[S];
@@ -296,7 +342,7 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
         const size_t base = tile0 + (size_t)s * BLOCK * ITEMS + (size_t)threadIdx.x * ITEMS;
         vx[s] = make_float4(0, 0, 0, 0); vy[s] = vx[s]; vz[s] = vx[s];
         vw[s] = make_uint4(0, 0, 0, 0);
-        m[s] = lane_mask<true>(p, x, y, z, rgbt, base, n, vx[s], vy[s], vz[s], vw[s]);
+        m[s] = lane_mask_lazy(p, x, y, z, rgbt, base, n, vx[s], vy[s], vz[s], vw[s]);
         inc[s] = __popc(m[s]);
     }
     // ranks inside the tile (points run step-major, then lane-major): wave prefixes, one barrier
@@ -321,21 +367,50 @@ __global__ void __launch_bounds__(BLOCK) compact_scatter_kernel(PredArgs p, cons
             if (w < wave) before += t;
             tot += t;
         }
-        size_t pos = out0 + run + before + inc[s];
+        // r4: the wave's kept points of this step -- a run of the output, wave_total long from wave_pos0 on -- go through LDS in output
+        // order and out in 16-byte stores (1 KiB per wave instruction and plane) with a scalar head and tail around the aligned part.
+        // (Rounds 1-3 had every lane store its own points, 4 bytes at a time at a lane stride of up to 16: the scatter kernel of a
+        // tile filter that keeps half of 10 M points ran at 3.3 TB/s, a plain copy of the same planes at 5.)
+        const uint32_t wave_total = wave_sum[s][wave];
+        const size_t wave_pos0 = out0 + run + before;
         run += tot;
-        const float ax[4] = {vx[s].x, vx[s].y, vx[s].z, vx[s].w}, ay[4] = {vy[s].x, vy[s].y, vy[s].z, vy[s].w};
-        const float az[4] = {vz[s].x, vz[s].y, vz[s].z, vz[s].w};
-        const uint32_t aw[4] = {vw[s].x, vw[s].y, vw[s].z, vw[s].w};
+        if (wave_total == 0) continue;   // (wave-uniform)
+        {
+            const float ax[4] = {vx[s].x, vx[s].y, vx[s].z, vx[s].w}, ay[4] = {vy[s].x, vy[s].y, vy[s].z, vy[s].w};
+            const float az[4] = {vz[s].x, vz[s].y, vz[s].z, vz[s].w};
+            const uint32_t aw[4] = {vw[s].x, vw[s].y, vw[s].z, vw[s].w};
+            uint32_t at = inc[s];
 #pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            if (m[s] & (1u << j)) {
-                ox[pos] = ax[j];
-                oy[pos] = ay[j];
-                oz[pos] = az[j];
-                ow[pos] = aw[j];
-                pos++;
+            for (int j = 0; j < ITEMS; j++) {
+                if (m[s] & (1u << j)) {
+                    stage[wave][0][at] = __float_as_uint(ax[j]);
+                    stage[wave][1][at] = __float_as_uint(ay[j]);
+                    stage[wave][2][at] = __float_as_uint(az[j]);
+                    stage[wave][3][at] = aw[j];
+                    at++;
+                }
             }
         }
+        // (LDS operations of one wave are carried out in the order they were issued: no barrier, but the compiler must keep the order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t head = min(wave_total, (uint32_t)((4u - (uint32_t)(wave_pos0 & 3u)) & 3u));
+        const uint32_t quads = (wave_total - head) >> 2, tail0 = head + 4u * quads;
+        float *const outs[4] = {ox, oy, oz, reinterpret_cast<float *>(ow)};
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++) {
+            float *const o = outs[pl] + wave_pos0;
+            const uint32_t *const st = stage[wave][pl];
+            if ((uint32_t)lane < head) o[lane] = __uint_as_float(st[lane]);
+            if ((uint32_t)lane < quads) {
+                const uint32_t i = head + 4u * (uint32_t)lane;
+                *reinterpret_cast<float4 *>(o + i) = make_float4(__uint_as_float(st[i]), __uint_as_float(st[i + 1]), __uint_as_float(st[i + 2]), __uint_as_float(st[i + 3]));
+            }
+            if (tail0 + (uint32_t)lane < wave_total) o[tail0 + lane] = __uint_as_float(st[tail0 + lane]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -366,7 +441,10 @@ void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_cou
 bool compact_count_scan(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, uint32_t *ticket, unsigned long long *total_host, uint32_t tag,
                         hipStream_t s) {
     size_t nb = compact_blocks(src.npoints);
-    if (!nb || src.npoints > SMALL_CLOUD || !ticket) return false;   // (bigger clouds: the two launches)
+    // Small clouds only.  (r4: tried at every size -- 2441 workgroups for 10 M points, each with its release / acquire around the one
+    // ticket word: tilefilter 81 -> 129 us, crop 70 -> 147.  An agent-scope release writes the XCD's L2 back, and all tickets
+    // are one address at the memory side.)
+    if (!nb || src.npoints > SMALL_CLOUD || !ticket) return false;
     CW_LAUNCH("compact_count", compact_count_scan_kernel<SMALL_STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(), src.rgbt(),
               src.npoints, block_counts, ticket, total_host, tag);
     return true;
@@ -376,15 +454,25 @@ void compact_scan(uint32_t *block_counts, size_t nblocks, unsigned long long *to
     CW_LAUNCH("compact_scan", compact_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_host, tag);
 }
 
-void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s) {
+void compact_scatter(const DeviceSoA &src, const Predicate &p, const uint32_t *block_offsets, const DeviceSoA &dst, hipStream_t s, unsigned long long *total_host,
+                     uint32_t tag) {
     size_t nb = compact_blocks(src.npoints);
     if (!nb) return;
+    // total_host != nullptr: block_offsets hold the count kernel's counts as they are (see the kernel)
     if (src.npoints <= SMALL_CLOUD) {
-        CW_LAUNCH("compact_scatter", compact_scatter_kernel<SMALL_STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
-                  src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt());
+        if (total_host) {
+            CW_LAUNCH("compact_scatter", (compact_scatter_kernel<SMALL_STEPS, true>), dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+                      src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt(), total_host, tag);
+        } else {
+            CW_LAUNCH("compact_scatter", (compact_scatter_kernel<SMALL_STEPS, false>), dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+                      src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt(), total_host, tag);
+        }
+    } else if (total_host) {
+        CW_LAUNCH("compact_scatter", (compact_scatter_kernel<STEPS, true>), dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+                  src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt(), total_host, tag);
     } else {
-        CW_LAUNCH("compact_scatter", compact_scatter_kernel<STEPS>, dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
-                  src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt());
+        CW_LAUNCH("compact_scatter", (compact_scatter_kernel<STEPS, false>), dim3((unsigned)nb), dim3(BLOCK), 0, s, to_args(p), src.x(), src.y(), src.z(),
+                  src.rgbt(), src.npoints, block_offsets, dst.x(), dst.y(), dst.z(), dst.rgbt(), total_host, tag);
     }
 }
 
