@@ -2866,6 +2866,23 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
 
 size_t voxel_workspace_bytes() { return g_workspace_bytes.load(); }
 
+// The workspaces that threads which have ended left for the next threads (at most eight) go back to the device.  For a
+// deployment that wants the memory back after a burst of threads, and for tests that measure a footprint.
+size_t voxel_release_pooled_workspaces() {
+    std::vector<Workspace *> gone;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_pool_mutex);
+        gone.swap(*g_ws_pool);
+    }
+    if (!gone.empty()) (void)hipDeviceSynchronize();
+    for (Workspace *w : gone) {
+        if (w->pending) (void)w->pending->outcome();   // (a result somebody still holds reads its report from this workspace's words)
+        delete w;
+    }
+    return gone.size();
+}
+
 }  // namespace cwipc_amd
 
 extern "C" _CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_bytes(void) { return cwipc_amd::voxel_workspace_bytes(); }
+extern "C" _CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_trim(void) { return cwipc_amd::voxel_release_pooled_workspaces(); }

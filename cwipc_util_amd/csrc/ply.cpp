@@ -147,7 +147,8 @@ bool read_ply(const char *filename, std::vector<cwipc_point> &out, std::string &
             if (ix < 0 || iy < 0 || iz < 0) { why = "vertex element without x, y, z"; return false; }
             size_t row_bytes = 0;   // the least a row can take: one byte per value in ASCII (digit + separator), the scalars' sizes in binary
             for (const PlyProperty &pr : e.props) row_bytes += format == 0 ? 2 : (pr.is_list ? kTypes[pr.count_type].size : kTypes[pr.type].size);
-            if (row_bytes == 0 || e.count > bytes_left / row_bytes) { why = "element vertex claims more rows than the file can hold"; return false; }
+            // (ASCII: the last value of the file need not be followed by a newline: one byte of grace)
+            if (row_bytes == 0 || e.count > (bytes_left + (format == 0 ? 1 : 0)) / row_bytes) { why = "element vertex claims more rows than the file can hold"; return false; }
             out.reserve(e.count);
         }
         std::vector<double> vals(e.props.size());

@@ -196,6 +196,7 @@ _SIGNATURES: Dict[str, Tuple[list, Any]] = {
     'cwipc_hip_synchronize': ([], None),
     'cwipc_hip_pool_bytes': ([], _c.c_size_t),
     'cwipc_hip_pool_trim': ([], None),
+    'cwipc_hip_workspace_trim': ([], _c.c_size_t),
     'cwipc_hip_host_alloc': ([_c.c_size_t], _c.c_void_p),
     'cwipc_hip_host_free': ([_c.c_void_p], None),
     'cwipc_hip_host_register': ([_c.c_void_p, _c.c_size_t], _c.c_int),

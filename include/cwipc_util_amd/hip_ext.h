@@ -26,6 +26,7 @@ _CWIPC_UTIL_EXPORT void cwipc_hip_synchronize(void);          /* wait for the ca
 _CWIPC_UTIL_EXPORT size_t cwipc_hip_pool_bytes(void);         /* bytes currently held by the device memory pool */
 _CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_bytes(void);    /* device bytes held by the voxel filter's workspaces (leaf grids; two per thread that downsamples) */
 _CWIPC_UTIL_EXPORT void cwipc_hip_pool_trim(void);            /* return cached device memory to the driver */
+_CWIPC_UTIL_EXPORT size_t cwipc_hip_workspace_trim(void);     /* give back the voxel workspaces that ended threads left for the next ones (at most 8); returns how many */
 
 /* ---- page-locked host buffers of the caller (round 4) ----
  * The copy path of the reference (src/cwipc_util.cpp:329-354 from_points, :226-250 copy_uncompressed) moves bytes between the

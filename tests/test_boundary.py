@@ -172,6 +172,11 @@ def test_ply_reader_takes_other_writers_files(cwipc, tmp_path):
                          b"property uchar alpha\nproperty short extra\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n" + body)
     got = cwipc.cwipc_read(fn, 1).get_numpy_array()
     assert got.tolist() == [(1.5, 2.5, -4.0, 1, 2, 3, 64), (0.25, 0.0, 8.0, 9, 8, 7, 128)]
+    # single-character values and no newline behind the last one: 2 bytes per value but for the very last (round 3's review)
+    fn = str(tmp_path / "tight.ply")
+    open(fn, "wb").write(b"ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n4 5 6")
+    got = cwipc.cwipc_read(fn, 1).get_numpy_array()
+    assert [(p[0], p[1], p[2]) for p in got.tolist()] == [(1.0, 2.0, 3.0), (4.0, 5.0, 6.0)]
 
 
 def test_ply_errors_are_loud(cwipc, tmp_path):

@@ -226,9 +226,11 @@ def test_config5_eight_threads_workspace_footprint(gpu):
     from cwipc_util_amd.capture import capture_tile
     from cwipc_util_amd.filters import factory
     dll = gpu.util.cwipc_util_dll_load()
-    # (what threads of earlier tests still hold -- an executor's workers live until they are collected -- is theirs, not this test's)
+    # what threads of earlier tests left in the pool of workspaces goes back to the device first (cwipc_hip_workspace_trim, r4), so that the
+    # bound below is about THIS test's eight threads; what live threads of earlier tests hold (an executor's workers) is measured and taken off
     gc.collect()
     dll.cwipc_hip_synchronize()
+    dll.cwipc_hip_workspace_trim()
     held_before = dll.cwipc_hip_workspace_bytes()
     tiles = [capture_tile(300_000, t, NTILES) for t in range(NTILES)]
     counts, errors = {}, []
@@ -257,7 +259,7 @@ def test_config5_eight_threads_workspace_footprint(gpu):
     dll.cwipc_hip_synchronize()
     held = dll.cwipc_hip_workspace_bytes()
     # eight threads' workspaces of 16 grids (0.32 GB each) on top of what was there, or ten in all when nothing was
-    assert held <= max(3.5 * 10**9, held_before + 2.7 * 10**9), (held, held_before)
+    assert held - held_before <= 2.7 * 10**9, (held, held_before)   # (round 3: max(3.5e9, held_before + 2.7e9), which forgave whatever was there before)
 
 
 @pytest.fixture(scope="module")

@@ -1011,6 +1011,40 @@ def test_downsample_stream_of_frames_returns_early(gpu, oracle, synth):
     assert gpu.cwipc_dangling_allocations(False) >= 0
 
 
+def test_pending_results_outlive_their_threads(gpu, oracle, synth):
+    """A downsample in a stream of calls is handed out while its kernels run; the report it settles on lies in page-locked words
+    of the calling thread's workspace.  Threads that have ended leave at most eight workspaces for the next threads -- the rest is
+    given back to the device, words included (round 3).  A result that outlives its thread, and its thread's workspace, must still
+    settle (round 3's review: the report was read from freed memory): twelve threads downsample once each -- their workspaces come
+    from the pool with a streak of good passes, so the call returns early -- hand the result over and end; then the counts are asked for."""
+    import threading
+    pts, cs = synth(300000, 0.2)
+    exp, _ = oracle.downsample(pts, cs, 0.01)
+    pc = make_cloud(gpu, pts, cs, 3)
+    gpu.cwipc_hip_upload(pc)
+
+    def warm():
+        for _ in range(5):
+            gpu.cwipc_downsample(pc, 0.01).count()
+    for _ in range(2):                       # two generations of threads: the pool holds workspaces that have seen this kind of call
+        ws = [threading.Thread(target=warm) for _ in range(12)]
+        for t in ws: t.start()
+        for t in ws: t.join()
+    results = [None] * 12
+
+    def once(i):
+        results[i] = gpu.cwipc_downsample(pc, 0.01)
+
+    ts = [threading.Thread(target=once, args=(i,)) for i in range(12)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    gpu.util.cwipc_util_dll_load().cwipc_hip_synchronize()
+    for r in results:
+        assert r.count() == len(exp)
+        got = r.get_numpy_array()
+        assert (got['tile'] == exp['tile']).all() and np.abs(got['x'].astype(np.float64) - exp['x']).max() <= XYZ_TOL
+
+
 def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
     """The lean accumulate kernel and the general one share one quantisation: bit-identical clouds (the general one is forced
     through CWIPC_VOXEL_GENERAL in a process of its own)."""
