@@ -366,6 +366,12 @@ bool ThreadCtx::ensure() {
             retire_stream(device, stream_alt);
             stream_alt = nullptr;
         }
+        for (hipStream_t &s : stream_extra) {
+            if (!s) continue;
+            (void)hipStreamSynchronize(s);
+            retire_stream(device, s);
+            s = nullptr;
+        }
         if (dev_words) { (void)hipFree(dev_words); dev_words = nullptr; }
         if (tickets) { (void)hipFree(tickets); tickets = nullptr; }
     }
@@ -379,6 +385,18 @@ bool ThreadCtx::ensure() {
     CW_HIP_TRY(hipMalloc((void **)&tickets, 16 * sizeof(uint32_t)));
     CW_HIP_TRY(hipMemset(tickets, 0, 16 * sizeof(uint32_t)));   // (once per thread; done before any of the thread's streams uses them)
     return true;
+}
+
+hipStream_t ThreadCtx::extra_stream(int i) {
+    if (i < 0 || i >= EXTRA_STREAMS) return nullptr;
+    if (!stream_extra[i]) {
+        stream_extra[i] = retired_stream_take(device);
+        if (!stream_extra[i] && hipStreamCreateWithFlags(&stream_extra[i], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            stream_extra[i] = nullptr;
+        }
+    }
+    return stream_extra[i];
 }
 
 void *ThreadCtx::staging(size_t bytes) {
@@ -420,6 +438,11 @@ bool ThreadCtx::sync() {
         const hipError_t e2 = hipStreamSynchronize(stream_alt);
         if (e == hipSuccess) e = e2;
     }
+    for (hipStream_t s : stream_extra) {
+        if (!s) continue;
+        const hipError_t e2 = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = e2;
+    }
     for (void *p : deferred) pool_free(p);   // (their kernels are done, or the stream is beyond help)
     deferred.clear();
     if (e != hipSuccess) return hip_failed(e, "hipStreamSynchronize(stream)", __FILE__, __LINE__);
@@ -436,6 +459,11 @@ ThreadCtx::~ThreadCtx() {
     if (stream_alt) {
         (void)hipStreamSynchronize(stream_alt);
         retire_stream(device, stream_alt);
+    }
+    for (hipStream_t s : stream_extra) {
+        if (!s) continue;
+        (void)hipStreamSynchronize(s);
+        retire_stream(device, s);
     }
     if (pinned) (void)hipHostFree(pinned);
     if (host_words) (void)hipHostFree(host_words);

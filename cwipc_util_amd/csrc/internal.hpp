@@ -81,6 +81,10 @@ struct ThreadCtx {
     // finalize kernel of one call, in flight when the call returns, does not hold up the first kernel of
     // the next.  Everything else runs on `stream`; sync() waits for both.
     hipStream_t stream_alt = nullptr;
+    // ... and a third and fourth (r4), created when a thread's downsample calls come faster than two workspaces turn around
+    static constexpr int EXTRA_STREAMS = 2;
+    hipStream_t stream_extra[EXTRA_STREAMS] = {nullptr, nullptr};
+    hipStream_t extra_stream(int i);   // stream_extra[i], created on first use (nullptr on failure)
     void *pinned = nullptr;       // staging for H2D/D2H of AoS points
     size_t pinned_bytes = 0;
     uint32_t *host_words = nullptr;   // 64 pinned 32-bit words for small read-backs

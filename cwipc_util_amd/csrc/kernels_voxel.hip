@@ -1950,8 +1950,9 @@ struct Workspace {
 std::mutex g_ws_pool_mutex;
 std::vector<Workspace *> *g_ws_pool = new std::vector<Workspace *>();   // never destroyed: threads may end after the statics
 
+constexpr int MAX_WS = 2 + ThreadCtx::EXTRA_STREAMS;   // workspaces (and streams) a thread's calls rotate over, at most
 struct WorkspaceLease {
-    Workspace *ws[2] = {nullptr, nullptr};
+    Workspace *ws[MAX_WS] = {nullptr, nullptr, nullptr, nullptr};
     Workspace &get(int which) {
         if (!ws[which]) {
             const int dev = current_device();
@@ -1969,19 +1970,21 @@ struct WorkspaceLease {
     }
     ~WorkspaceLease() {
         // thread exit: a finalize kernel of this thread's last call may still be using a workspace
-        if (ws[0] || ws[1]) (void)hipDeviceSynchronize();
+        bool any = false;
+        for (int i = 0; i < MAX_WS; i++) any = any || ws[i];
+        if (any) (void)hipDeviceSynchronize();
         // A pass of this thread that was handed out while it ran (ws.pending) reads its report from the workspace's pinned words
         // when somebody asks for the result -- possibly another thread, long after this one has gone and the workspace with
         // it.  The report is final now: take it (the outcome is cached in the pending pass, the words are not looked at again).
         // A workspace that goes to the pool keeps its `pending`: its next user learns from it whether the records were left clean.
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MAX_WS; i++)
             if (ws[i] && ws[i]->pending) (void)ws[i]->pending->outcome();
         // (r3: at most eight wait here -- a program with a thread per tile and frame finds one each; what threads held beyond
         // that, mostly second workspaces that a busy moment made them take, is given back to the device)
         std::vector<Workspace *> surplus;
         {
             std::lock_guard<std::mutex> lock(g_ws_pool_mutex);
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < MAX_WS; i++) {
                 if (!ws[i]) continue;
                 if (g_ws_pool->size() < 8) g_ws_pool->push_back(ws[i]);
                 else surplus.push_back(ws[i]);
@@ -1997,12 +2000,14 @@ thread_local int t_ws_idle = 0;   // calls in a row that found both of the threa
 // For the duration of a call: the thread's current stream is the one of the workspace in use.
 struct StreamOfWorkspace {
     ThreadCtx &c;
-    bool swapped;
-    StreamOfWorkspace(ThreadCtx &ctx, int which) : c(ctx), swapped(which == 1 && ctx.stream_alt != nullptr) {
-        if (swapped) std::swap(c.stream, c.stream_alt);
+    hipStream_t *other = nullptr;   // the stream that changed places with c.stream for the duration of the call
+    StreamOfWorkspace(ThreadCtx &ctx, int which) : c(ctx) {
+        if (which == 1 && c.stream_alt) other = &c.stream_alt;
+        else if (which >= 2 && c.extra_stream(which - 2)) other = &c.stream_extra[which - 2];
+        if (other) std::swap(c.stream, *other);
     }
     ~StreamOfWorkspace() {
-        if (swapped) std::swap(c.stream, c.stream_alt);
+        if (other) std::swap(c.stream, *other);
     }
 };
 
@@ -2178,29 +2183,44 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     ThreadCtx &c = tctx();
     if (!c.ensure()) return nullptr;
     const size_t n = src.npoints;
-    // Two workspaces (and streams) per thread, taken in turn, so that a call queued right behind another does not wait for
-    // that one's finalize kernel.  The second one comes into being only when it is needed: a thread whose downsample calls
-    // are separated by other work (a per-tile filter chain) finds its first workspace idle every time and never pays the
-    // 80+ MB of grids for a second.
-    int which = t_ws_next;
-    if (!t_ws.ws[1]) {
-        which = 0;
-        if (t_ws.ws[0] && c.stream && hipStreamQuery(c.stream) == hipErrorNotReady) which = 1;
+    // Workspaces (and streams) per thread, taken in turn, so that a call queued right behind another does not wait for that one's
+    // finalize kernel.  The second one comes into being only when it is needed: a thread whose downsample calls are separated by
+    // other work (a per-tile filter chain) finds its first workspace idle every time and never pays the 80+ MB of grids for a second.
+    // r4: and a third (CWIPC_WORKSPACES, 1 to 4, default 3) when the one whose turn it is still has kernels in flight: the kernel
+    // trace of a stream of calls (gpurun_out/r4_trace_dump.log) shows a call's chain on its stream -- accumulate 54-65 us next to its
+    // neighbour, replay 7, finalize 16-27, and the host's turn-around -- at ~110 us, i.e. two streams give a call every 55 us whatever
+    // the accumulate kernel does; the chip had nothing to stream for 12 of every 110 us.
+    static const int max_ws = []() { const char *e = getenv("CWIPC_WORKSPACES"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > MAX_WS ? MAX_WS : v; }();
+    int have = 0;
+    while (have < MAX_WS && t_ws.ws[have]) have++;
+    const auto stream_of = [&](int i) -> hipStream_t { return i == 0 ? c.stream : i == 1 ? c.stream_alt : c.extra_stream(i - 2); };
+    const auto busy = [&](int i) {
+        hipStream_t s = stream_of(i);
+        const bool b = s && hipStreamQuery(s) == hipErrorNotReady;
         (void)hipGetLastError();   // (hipErrorNotReady is an answer, not a failure)
-    } else if (c.stream && c.stream_alt && !t_ws.ws[1]->pending) {
-        // ... and goes again when it has not been needed for a while: sixteen calls in a row that found both streams idle (a
-        // thread that has stopped calling back to back: 0.3 GB of leaf grids it no longer needs)
-        const bool idle = hipStreamQuery(c.stream) == hipSuccess && hipStreamQuery(c.stream_alt) == hipSuccess;
-        (void)hipGetLastError();
-        t_ws_idle = idle ? t_ws_idle + 1 : 0;
-        if (t_ws_idle >= 16) {
-            delete t_ws.ws[1];
-            t_ws.ws[1] = nullptr;
-            t_ws_idle = 0;
-            which = 0;
+        return b;
+    };
+    int which = 0;
+    if (have > 0) {
+        which = t_ws_next % have;
+        if (have < max_ws && busy(which)) {
+            which = have;          // this thread's calls come faster than its workspaces turn around: one more
+        } else if (have > 1 && !t_ws.ws[have - 1]->pending) {
+            // ... and the last one goes again when it has not been needed for a while: sixteen calls in a row that found all streams idle (a
+            // thread that has stopped calling back to back: 0.3 GB of leaf grids it no longer needs)
+            bool idle = true;
+            for (int i = 0; i < have && idle; i++) idle = !busy(i);
+            t_ws_idle = idle ? t_ws_idle + 1 : 0;
+            if (t_ws_idle >= 16) {
+                delete t_ws.ws[have - 1];
+                t_ws.ws[have - 1] = nullptr;
+                have--;
+                t_ws_idle = 0;
+                which = which % have;
+            }
         }
     }
-    t_ws_next = which ^ 1;
+    t_ws_next = which + 1;
     Workspace &ws = t_ws.get(which);
     StreamOfWorkspace on_its_stream(c, which);
     if (ws.pending) {
@@ -2460,13 +2480,17 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
-            // r4, measured and NOT the default (profiles/r04_k1_dump_merge.txt): CWIPC_K1_DUMP=1 makes the accumulate kernel leave its
-            // tables' entries in the workspace, and a kernel of small workgroups right behind it takes them to the records
-            // (voxel_k1_fast.inc, fast_dump / voxel_merge_kernel).  The accumulate kernel alone: 53.4 -> 48.1 us; but the records'
-            // 112 k x 6 atomics, sent by all the merge workgroups at once, take the memory side as long as they take wherever they
-            // come from (merge kernel 20 us alone), a single call with count() 64.6 -> 78.7 us, a call in a stream 54.6 -> 60-69 us
-            // (the merge workgroups find no room beside the next call's accumulate kernel: 4 x 112 of a SIMD's 512 registers are taken)
-            static const bool dump_knob = []() { const char *e = getenv("CWIPC_K1_DUMP"); return e && atoi(e) != 0; }();
+            // r4: the accumulate kernel may leave its tables' entries in the workspace, for a kernel of small workgroups right behind it to
+            // take to the records (voxel_k1_fast.inc, fast_dump / voxel_merge_kernel): the accumulate kernel alone 53.4 -> 48.1 us, the merge
+            // kernel 20 us alone -- a loss for a call that is waited for (64.6 -> 78.7 us with count()), possibly a gain in a stream of calls,
+            // where the merge workgroups (one wave per SIMD, 64 registers, 19 KB of LDS) run beside the NEXT call's accumulate kernel.
+            // CWIPC_K1_DUMP: 0 never, 1 always, 2 when this call is going to return with its kernels in flight (a stream); default 0
+            // until the stream figure says otherwise (profiles/r04_k1_dump_merge.txt)
+            static const int dump_mode = []() { const char *e = getenv("CWIPC_K1_DUMP"); return e ? atoi(e) : 0; }();
+            static const bool defer_allowed = []() { const char *e = getenv("CWIPC_DEFER"); return !e || atoi(e) != 0; }();
+            const bool will_defer = deferred && defer_allowed && attempt == 0 && ws.streak >= 2 && !profiling_enabled() &&
+                                    (leaf_split ? ws.last_m > 0 : (ws.last_m_grid > 0 && ws.gwords_cap > 0));
+            const bool dump_knob = dump_mode == 1 || (dump_mode == 2 && will_defer);
             const size_t table_entries = pair ? (size_t)PAIR_LTAB : (size_t)LTAB;
             bool dump = dump_knob;
             if (dump && (ws.dump_blocks < fast_blocks || ws.dump_entries != table_entries)) {

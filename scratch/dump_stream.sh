@@ -1,0 +1,15 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+run() { # label, env...
+  label=$1; shift
+  env "$@" python3 bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --no-config4 --no-config3 --no-config5 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$label', 'K1 alone us', round(d['kernels']['voxel_accumulate']['ms_avg']*1e3,1), 'step us', round(d['ms_per_step']*1e3,1), 'Gpts/s', round(d['value']/1e3,1), 'call+count', {k:round(v,1) for k,v in d.get('call_then_count_us',{}).items() if k!='note'}, {k:round(v['ms_avg']*1e3,1) for k,v in d['kernels'].items()})"
+}
+run direct CWIPC_K1_DUMP=0
+run auto CWIPC_K1_DUMP=2
+run auto_spare0 CWIPC_K1_DUMP=2 CWIPC_SPARE_CUS=0
+run auto_spare16 CWIPC_K1_DUMP=2 CWIPC_SPARE_CUS=16
+run always CWIPC_K1_DUMP=1
+run direct CWIPC_K1_DUMP=0
+run auto CWIPC_K1_DUMP=2

@@ -25,9 +25,20 @@ STANDIN_DIR = os.path.join(ROOT, "tests", "standin", "lib")
 CHILD = os.path.join(ROOT, "tests", "standin", "ranks_child.py")
 
 
+def ensure_standin():
+    """The stand-in build is made of the product's objects: one that is older than the product (or missing) is rebuilt here
+    (tests/standin/build_standin.py; hipcc is on the GPU box too)."""
+    lib = os.path.join(STANDIN_DIR, "libcwipc_util.so")
+    product = os.path.join(ROOT, "cwipc_util_amd", "lib", "libcwipc_util.so")
+    if os.path.exists(lib) and os.path.exists(product) and os.path.getmtime(lib) >= os.path.getmtime(product):
+        return
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "standin", "build_standin.py")], capture_output=True, text=True, timeout=900)
+    if proc.returncode != 0 or not os.path.exists(lib):
+        pytest.fail("tests/standin/lib/libcwipc_util.so could not be built:\n" + proc.stdout[-1000:] + proc.stderr[-3000:])
+
+
 def run_ranks(tmp_path, world, mode, scenario, faults=None, timeout=300):
-    if not os.path.exists(os.path.join(STANDIN_DIR, "libcwipc_util.so")):
-        pytest.fail("tests/standin/lib/libcwipc_util.so is missing: run python tests/standin/build_standin.py (or __graft_entry__.build())")
+    ensure_standin()
     env = dict(os.environ, CWIPC_LIBRARY_DIR=STANDIN_DIR, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("CWIPC_TEST_EXCHANGE_FAULTS", None)
     if faults:
@@ -81,6 +92,7 @@ def test_the_stand_in_notices_an_unmatched_rank(tmp_path):
     """The checker checks: a rank that is struck out of a frame on ITS side only (a fault the others cannot see would be exactly
     round 2's bug) must not pass.  Here: world 2, but only one of the two ranks is started -- creation is collective, the rank
     gives up its rendezvous and the child ends with an error instead of hanging or succeeding."""
+    ensure_standin()
     env = dict(os.environ, CWIPC_LIBRARY_DIR=STANDIN_DIR, HSA_ENABLE_IPC_MODE_LEGACY="0")
     code = (
         "import sys; sys.path.insert(0, %r)\n"
