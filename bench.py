@@ -739,6 +739,11 @@ def main() -> None:
                 "frac_pipelined": algorithmic_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
                 "achieved_all_kernels": algorithmic_bytes / (all_ms * 1e-3) / 1e9,
                 "frac_all_kernels": algorithmic_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "note": "achieved / frac / kernel_ms_avg: hipEvents around the dominant kernel in a second pass over the same steps, every call "
+                        "waited for, so the kernel runs ALONE (the events add ~3 us to what a kernel trace gives it).  In the timed region a "
+                        "thread's calls rotate over three workspaces and streams and up to three accumulate kernels are in flight at once: a "
+                        "call completes every ms_per_step (achieved_pipelined), while a kernel's own duration in a trace of that region is "
+                        "longer than alone -- profiles/rNN_bench_rocprofv3_summary.txt gives both parts and the run with one workspace",
             },
             "kernels": kernels,
         }

@@ -13,7 +13,7 @@ for _ in range(4):   # 640 MB: more than the Infinity Cache
     pc = cw.cwipc_from_numpy_array(pts, 1); pc._set_cellsize(cs); cw.cwipc_hip_upload(pc, drop_host_copy=True); pcs.append(pc)
 res = {}
 def stream(f, reps=100):
-    for i in range(10): f(pcs[i % 4])
+    for i in range(40): f(pcs[i % 4])   # (a thread whose downsample calls come back to back takes a second and a third workspace: 0.3 GB each, allocated once)
     sync(); t0 = time.perf_counter()
     for i in range(reps): out = f(pcs[i % 4])   # the previous result is released while this one is being made
     sync(); return (time.perf_counter() - t0) / reps

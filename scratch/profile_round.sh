@@ -19,6 +19,11 @@ cp $OUT/${R}_traffic.json profiles/${R}_traffic.json      # (this box's copy of 
 # the bench line as the driver runs it (all sub-records, CPU baseline)
 python3 bench.py > $OUT/${R}_bench_line.json 2> $OUT/bench_line.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 200 --warmup 20 $FLAGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err || exit 1
+# r4: in the timed region up to three accumulate kernels are in flight at once (three workspaces and streams per thread): a kernel's
+# own duration in the trace above is then longer than alone although calls complete faster.  The same trace with ONE workspace
+# (CWIPC_WORKSPACES=1: every kernel of a call behind the call before, nothing overlaps): what the kernels take on their own.
+CWIPC_WORKSPACES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_one -- python3 bench.py --steps 200 --warmup 20 $FLAGS > $OUT/bench_trace_one.json 2> $OUT/bench_trace_one.err || exit 1
+cp $(find $OUT/trace_one -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats_one_workspace.csv
 python3 scratch/profile_summary.py $OUT $R > $OUT/${R}_bench_rocprofv3_summary.txt || exit 1
 bash scratch/pmc_k1_r02.sh pmc_k1_$R > $OUT/pmc_k1.log 2>&1
 cp gpurun_out/pmc_k1_$R.txt $OUT/${R}_k1_pmc.txt

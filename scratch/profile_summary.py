@@ -12,6 +12,20 @@ if not traffic_only:
             d = json.loads(l)
             print("# bench line under the profiler: value %.1f %s, ms_per_step %.4f, roofline.kernel_ms_avg %.4f (hipEvents)" % (
                 d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms_avg"]))
+    print("# READ THIS FIRST (r4): a thread's downsample calls rotate over up to three workspaces and streams, so in the timed region of the bench")
+    print("# (a stream of 200 calls) up to three accumulate kernels are in flight at once.  A kernel's OWN duration in that part of the trace is")
+    print("# longer than alone (its workgroups share the chip with its neighbours') while calls COMPLETE faster: the rate is the start-to-start")
+    print("# interval.  The csv's average mixes that part with the bench's second pass (every call waited for, the kernel alone).  Both parts are")
+    print("# given below, and the same run with ONE workspace (nothing overlaps) is in %s_bench_kernel_stats_one_workspace.csv." % rnd)
+    one = os.path.join(out, rnd + "_bench_kernel_stats_one_workspace.csv")
+    if os.path.exists(one):
+        for r in csv.DictReader(open(one)):
+            if "voxel_accumulate" in r["Name"] and "general" not in r["Name"] and "<1" in r["Name"]:
+                print("# one workspace (CWIPC_WORKSPACES=1): accumulate kernel %s calls, average %.0f ns, min %s ns" % (r["Calls"], float(r["AverageNs"]), r["MinNs"]))
+        for l in open(os.path.join(out, "bench_trace_one.json")):
+            if l.startswith("{"):
+                d1 = json.loads(l)
+                print("# one workspace, bench line under the profiler: ms_per_step %.4f" % d1["ms_per_step"])
     stats = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
     for f in stats:
         shutil.copyfile(f, os.path.join(out, rnd + "_bench_kernel_stats.csv"))
@@ -29,6 +43,18 @@ if not traffic_only:
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
             tail = v[-40:]
             print("%-70s n=%5d last40_avg=%10.0f" % (k[:70], len(v), sum(tail) / len(tail)))
+        # r4: the accumulate kernel in the two parts of the run.  In the timed region (a stream of calls on three streams) consecutive
+        # accumulate kernels overlap on the chip: a kernel's own duration is LONGER than alone while calls complete FASTER -- the rate is
+        # the start-to-start interval; in the second pass every call is waited for and the kernel runs alone.
+        k1 = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))
+                    if "voxel_accumulate" in r["Kernel_Name"] and "general" not in r["Kernel_Name"])
+        if len(k1) >= 426:
+            timed = k1[26:226]          # 20 warm-up + 4 sizing calls + a margin, then the 200 timed steps
+            alone = k1[-200:]
+            print("## accumulate kernel, timed region (stream of calls): start-to-start %.0f ns, own duration %.0f ns (neighbours overlap)" % (
+                (timed[-1][0] - timed[0][0]) / (len(timed) - 1), sum(e - s for s, e in timed) / len(timed)))
+            print("## accumulate kernel, second pass (every call waited for, the kernel alone): duration %.0f ns, min %d" % (
+                sum(e - s for s, e in alone) / len(alone), min(e - s for s, e in alone)))
     for name in ("fetch", "write"):
         for f in glob.glob(out + f"/{name}/**/*counter_collection.csv", recursive=True):
             agg = collections.defaultdict(lambda: collections.defaultdict(list))

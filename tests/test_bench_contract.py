@@ -40,12 +40,14 @@ def test_committed_profile_files_are_from_one_run():
         import pytest
         pytest.skip("round 2's files predate the single-run script")
     rows = list(csv.DictReader(open(os.path.join(prof, newest + "_bench_kernel_stats.csv"))))
-    k1 = [r for r in rows if "voxel_accumulate" in r["Name"] and "general" not in r["Name"]]
+    # (the headline's accumulate kernel is the octree variant, template argument MODE = 1; since round 4 the run also holds the plain-grid
+    # variant <0, ...> of the call-then-count figure for a negative cell size)
+    k1 = [r for r in rows if "voxel_accumulate" in r["Name"] and "general" not in r["Name"] and "kernel<0" not in r["Name"]]
     assert len(k1) == 1, [r["Name"] for r in k1]
     avg_csv = float(k1[0]["AverageNs"])
     summary = open(os.path.join(prof, newest + "_bench_rocprofv3_summary.txt")).read()
     # (the kernel's name as the csv has it -- "void cwipc_amd::(anonymous namespace)::voxel_accumulate_fast_kernel<1>..." -- holds blanks)
-    m = re.search(r"^[^\n]*voxel_accumulate(?!_general)[^\n]*?\s+(\d+)\s+(\d+)\s+(\d+)\s+\d+\s+\d+\s+[\d.]+\s*$", summary, re.M)
+    m = re.search(r"^[^\n]*voxel_accumulate(?!_general)(?!_fast_kernel<0)[^\n]*?\s+(\d+)\s+(\d+)\s+(\d+)\s+\d+\s+\d+\s+[\d.]+\s*$", summary, re.M)
     assert m, "no accumulate-kernel row in the summary"
     assert int(m.group(1)) == int(k1[0]["Calls"]) and abs(int(m.group(3)) - avg_csv) <= 1.0, (m.groups(), avg_csv)
     assert "# bench line under the profiler:" in summary
