@@ -300,6 +300,9 @@ JoinOutcome join_frame(cwipc_hip_comm *cm, std::shared_ptr<DeviceSoA> src, uint6
         uint32_t *status_host = reinterpret_cast<uint32_t *>(cm->meta_host + 1 + W);   // [0] ours, [1 .. W] everybody's
         uint32_t *status_dev = reinterpret_cast<uint32_t *>(cm->meta_dev + 1 + W);
         status_host[0] = word;
+        // (the one exit between the gathers that is not a collective decision: a HIP or RCCL call of the second gather itself failed on
+        // this rank -- a lost device, a broken communicator.  The other ranks are then inside a collective that cannot complete either;
+        // nothing this rank could send would reach them.  Every other way out of a frame is taken by all ranks alike, from the records.)
         if (!gather_words(cm, status_host, status_dev, status_dev + 1, status_host + 1, 1, who)) return none;
         for (int r = 0; r < W; r++)
             if (all[r].status == xplan::ST_OK) all[r].status = status_host[1 + r];

@@ -1069,7 +1069,7 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
 
 
 @pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0",
-                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_PAIR=1"])
+                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4"])
 def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
     """Every environment knob of the shipped library selects another way to the same result: a
     process with the knob set must produce, bit for bit, what this process produces -- a stream of downsample calls (the
@@ -1085,7 +1085,8 @@ def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
         "import cwipc_util_amd as cw\n"
         "pts = np.load(%r); out = {}\n"
         "pc = cw.cwipc_from_numpy_array(pts, 1); pc._set_cellsize(%r)\n"
-        "for i in range(6): out['down%%d' %% i] = cw.cwipc_downsample(pc, 0.01).get_numpy_array()\n"
+        "outs = [cw.cwipc_downsample(pc, 0.01) for i in range(14)]\n"
+        "for i, o in enumerate(outs): out['down%%d' %% i] = o.get_numpy_array()\n"
         "perm = pts[np.random.default_rng(3).permutation(len(pts))]\n"
         "pp = cw.cwipc_from_numpy_array(perm, 1); pp._set_cellsize(%r)\n"
         "for i in range(6): out['perm%%d' %% i] = cw.cwipc_downsample(pp, 0.01).get_numpy_array()\n"
