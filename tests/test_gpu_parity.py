@@ -38,6 +38,31 @@ def test_upload_download_roundtrip(gpu, oracle, synth, npoints):
     assert same(gpu.cwipc_from_packet(pkt).get_numpy_array(), pts)
 
 
+def test_page_locked_buffers_both_ways(gpu, synth, tmp_path):
+    """The upload from a page-locked buffer has two ways (DMA + kernel, the default; the kernel reading the host buffer,
+    CWIPC_PINNED_UPLOAD=kernel): the same cloud either way."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pts, cs = synth(200000, 0.3)
+    np.save(str(tmp_path / "pts.npy"), pts)
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import cwipc_util_amd as cw\n"
+        "pts = np.load(%r)\n"
+        "p = cw.cwipc_hip_pinned_points(len(pts) + 5); p[5:] = pts\n"
+        "pc = cw.cwipc_from_numpy_array(p[5:], 1); p[:] = np.zeros(1, dtype=p.dtype)[0]\n"
+        "assert pc.get_numpy_array().tobytes() == pts.tobytes()\n"
+        "np.save(sys.argv[1], cw.cwipc_tilefilter(pc, 2).get_numpy_array())\n"
+    ) % (root, str(tmp_path / "pts.npy"))
+    outs = []
+    for mode in ("dma", "kernel"):
+        out = str(tmp_path / (mode + ".npy"))
+        subprocess.run([sys.executable, "-c", code, out], check=True, timeout=600, env=dict(os.environ, CWIPC_PINNED_UPLOAD=mode))
+        outs.append(np.load(out))
+    assert same(outs[0], outs[1]) and same(outs[0], pts[pts['tile'] == 2])
+
+
 def test_page_locked_buffers_of_the_caller(gpu, oracle, synth):
     """Round 4, the copy path with buffers the DMA engines can reach (include/cwipc_util_amd/hip_ext.h: cwipc_hip_host_alloc /
     cwipc_hip_host_register): cwipc_from_points reads such a buffer from the device where it lies and has finished with it when it
@@ -1069,7 +1094,7 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
 
 
 @pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0",
-                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4"])
+                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4"])   # (+ CWIPC_PINNED_UPLOAD=kernel: test_page_locked_buffers_both_ways)
 def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
     """Every environment knob of the shipped library selects another way to the same result: a
     process with the knob set must produce, bit for bit, what this process produces -- a stream of downsample calls (the
