@@ -2471,8 +2471,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             // of 5 steps, five busy waves each, instead of 74 workgroups whose sixteen waves queue up on four SIMDs.
             // CWIPC_K1_PAIR=1 (experiments): two workgroups of 8 waves and half the range per CU instead of one of 16 (voxel_k1_fast.inc)
             static const int pair_knob = []() { const char *e = getenv("CWIPC_K1_PAIR"); return e ? atoi(e) : 0; }();
+            // CWIPC_K1_PAIR=2: the 8-wave workgroups with FULL ranges, one per CU and kernel -- in a stream of calls a CU then holds a workgroup
+            // of each of two consecutive kernels, and one streams while the other sets up or flushes
             const bool pair = pair_knob != 0;
-            const size_t slots = (size_t)cus * (pair ? 2 : 1);
+            const size_t slots = (size_t)cus * (pair_knob == 1 ? 2 : 1);
             const size_t wg_steps = std::min<size_t>(std::max<size_t>((steps_total + slots - 1) / slots, 1), MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP);
             fast_blocks = (uint32_t)((steps_total + wg_steps - 1) / wg_steps);
             fast_per_wg = (uint32_t)(wg_steps * WAVE_STEP);
