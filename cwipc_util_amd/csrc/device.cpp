@@ -7,6 +7,7 @@
 // the pool and the profile table are the only shared state and are locked.
 #include "internal.hpp"
 
+#include <pthread.h>
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -210,20 +211,36 @@ struct CopyPool {
         for (auto &w : workers) w.detach();   // (they sleep on the queue; the process may end under them)
     }
 };
-CopyPool *copy_pool() {
-    static CopyPool *pool = []() {
-        unsigned hw = std::thread::hardware_concurrency();
-        return new CopyPool(hw >= 8 ? 3u : hw >= 4 ? 2u : 1u);   // never destroyed: threads may outlive the statics
-    }();
-    return pool;
+// (a process that forks takes the pool's memory along but not its threads: the child starts a pool of its own at its first big copy)
+std::atomic<CopyPool *> g_copy_pool{nullptr};
+std::mutex g_copy_pool_make;
+std::mutex *g_copy_calls = new std::mutex();   // one parallel copy at a time (the callers' own threads are the parallelism beyond that)
+void copy_pool_after_fork() {
+    g_copy_pool.store(nullptr);                 // the parent's pool object is abandoned in the child (its threads do not exist here)
+    new (&g_copy_pool_make) std::mutex();       // either mutex may have been held by a thread that is not in the child
+    g_copy_calls = new std::mutex();
 }
-std::mutex g_copy_calls;   // one parallel copy at a time (the callers' own threads are the parallelism beyond that)
+CopyPool *copy_pool() {
+    CopyPool *p = g_copy_pool.load(std::memory_order_acquire);
+    if (p) return p;
+    std::lock_guard<std::mutex> g(g_copy_pool_make);
+    p = g_copy_pool.load(std::memory_order_acquire);
+    if (!p) {
+        static bool registered = false;
+        if (!registered) { (void)pthread_atfork(nullptr, nullptr, copy_pool_after_fork); registered = true; }
+        const unsigned hw = std::thread::hardware_concurrency();
+        p = new CopyPool(hw >= 8 ? 3u : hw >= 4 ? 2u : 1u);   // never destroyed: threads may outlive the statics
+        g_copy_pool.store(p, std::memory_order_release);
+    }
+    return p;
+}
 }  // namespace
 
 void parallel_memcpy(void *dst, const void *src, size_t bytes) {
     const size_t min_piece = (size_t)256 << 10;
-    if (bytes < ((size_t)1 << 20) || std::thread::hardware_concurrency() < 2 || !g_copy_calls.try_lock()) { memcpy(dst, src, bytes); return; }
-    std::lock_guard<std::mutex> one(g_copy_calls, std::adopt_lock);
+    std::mutex *const calls = g_copy_calls;
+    if (bytes < ((size_t)1 << 20) || std::thread::hardware_concurrency() < 2 || !calls->try_lock()) { memcpy(dst, src, bytes); return; }
+    std::lock_guard<std::mutex> one(*calls, std::adopt_lock);
     CopyPool *pool = copy_pool();
     const size_t parts = std::min<size_t>(pool->workers.size() + 1, bytes / min_piece);
     const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;

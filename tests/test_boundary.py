@@ -359,6 +359,27 @@ def test_product_does_not_import_the_oracle():
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
 
 
+def test_big_copies_survive_a_fork(cwipc):
+    """Clouds of a megabyte and more are copied by a pool of threads that live as long as the process (round 4).  A forked child has the
+    pool's memory but not its threads: it must start its own instead of waiting for workers that do not exist."""
+    import signal
+    big = np.zeros(400000, dtype=cwipc.cwipc_point_numpy_dtype)
+    big['x'] = np.arange(400000)
+    cwipc.cwipc_from_numpy_array(big, 1)           # the parent's pool exists now
+    pid = os.fork()
+    if pid == 0:
+        try:
+            signal.alarm(30)
+            pc = cwipc.cwipc_from_numpy_array(big, 2)
+            out = np.zeros_like(big)
+            pc.copy_into(out)
+            os._exit(0 if (out['x'] == big['x']).all() else 3)
+        except BaseException:
+            os._exit(4)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+
+
 def test_shipped_library_holds_no_test_infrastructure():
     """The multi-rank exchange tests run a build of the library with an in-process stand-in for RCCL and fault hooks
     (tests/standin/).  The shipped library must hold neither: its RCCL entry points are undefined symbols that librccl serves,
