@@ -589,178 +589,12 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid gv, const Gr
     dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
 }
 
-// ---- k-NN for the dense layout (small and medium clouds), the neighbourhood of 64 queries staged in LDS (round 4) ----
-// The kernel above is one lane's chain of dependent loads per query: nine row lookups, then the candidates four at a time -- some fifty
-// round trips to L2, 39-42 us for the 36 k points of a camera tile however the queries are spread (round 3 tried more loads in flight, four
-// lanes per query, the rows looked up together: nothing moved it).  Here a wave takes 64 consecutive points of the sorted array.  They lie
-// in consecutive cells [ca, cb] of the grid's linear order (x fastest), so for each of the nine row offsets (dy, dz) the cells their
-// neighbourhoods reach are ONE run of cells, [ca - 1, cb + 1] shifted by dy dimx + dz dimx dimy, i.e. one run of the sorted points (with
-// a few cells too many where a row ends: a superset).  The wave copies the nine runs into LDS with all its lanes at once -- one round trip
-// -- and every lane then scans ITS OWN three cells of each row there.  Same candidates per query, same order of rows, same skip rule,
-// same sorted insert as above: d_i is the same number.  A chunk whose runs do not fit (a dense spot next to a sparse one) and the rings
-// beyond the first (queries at the cloud's edge) read the points where they lie, as above.
-// (First version: a wave per ROW of cells, its queries 64 at a time: 61-67 us -- a row that runs along the surface holds 200 points
-// and more, four chunks one after the other, while the kernel above spreads them over several workgroups.)
-constexpr int KNN_STAGE = 1536;   // points staged per chunk (24 KB)
-
-template <int KCAP>
-__global__ void __launch_bounds__(64) knn_mean_dist_staged_kernel(const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
-                                                                 const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_count, int k,
-                                                                 float *__restrict__ dist_out, int no_stage) {
-    __shared__ float4 stage[KNN_STAGE];
-    const Grid g = gm->g;
-    const int lane = threadIdx.x;
-    const int want = k + 1, pad = KCAP - want;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const size_t chunk = (size_t)blockIdx.x * 64;
-    if (chunk >= n) return;
-    const size_t qi = chunk + (size_t)lane;
-    const bool active = qi < n;
-    const float4 q = sorted[active ? qi : chunk];
-    const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
-    // this lane's own three cells of each of the nine rows (rings 0 and 1): requested now, needed after the staging
-    auto row_range = [&](int xa, int xb, int yy, int zz, uint32_t &first, uint32_t &last) {
-        const uint32_t b = (uint32_t)g.dim[0] * ((uint32_t)yy + (uint32_t)g.dim[1] * (uint32_t)zz), c1 = b + (uint32_t)xb;
-        first = cell_start[b + (uint32_t)xa];
-        last = cell_start[c1] + cell_count[c1];
-    };
-    uint32_t first[9], last[9];
-    {
-        const int xa = max(cx - 1, 0), xb = min(cx + 1, g.dim[0] - 1);
-#pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
-            first[r] = last[r] = 0;
-            if (yy >= 0 && yy < g.dim[1] && zz >= 0 && zz < g.dim[2]) row_range(xa, xb, yy, zz, first[r], last[r]);
-        }
-    }
-    // the chunk's cells in the grid's linear order
-    const long long ncells = (long long)g.dim[0] * g.dim[1] * g.dim[2];
-    long long clo = (long long)cx + (long long)g.dim[0] * ((long long)cy + (long long)g.dim[1] * cz), chi = clo;
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long a = __shfl_xor(clo, off, 64), b = __shfl_xor(chi, off, 64);
-        clo = a < clo ? a : clo;
-        chi = b > chi ? b : chi;
-    }
-    // lanes 0..8: the run of sorted points that row offset r can reach; everybody learns all nine
-    uint32_t sf = 0, sl = 0;
-    if (lane < 9) {
-        const long long shift = (long long)((lane % 3) - 1) * g.dim[0] + (long long)((lane / 3) - 1) * g.dim[0] * g.dim[1];
-        long long lo = clo - 1 + shift, hi = chi + 1 + shift;
-        if (hi >= 0 && lo < ncells) {
-            lo = lo < 0 ? 0 : lo;
-            hi = hi >= ncells ? ncells - 1 : hi;
-            sf = cell_start[lo];
-            sl = cell_start[hi] + cell_count[hi];
-        }
-    }
-    uint32_t seg_first[9], seg_off[9], total = 0;
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-        seg_first[r] = (uint32_t)__shfl((int)sf, r, 64);
-        seg_off[r] = total;
-        total += (uint32_t)__shfl((int)sl, r, 64) - seg_first[r];
-    }
-    const bool staged = total <= (uint32_t)KNN_STAGE && !no_stage;
-    if (staged) {
-        for (uint32_t i = (uint32_t)lane; i < total; i += 64u) {
-            int r = 0;
-#pragma unroll
-            for (int t = 1; t < 9; t++) r = i >= seg_off[t] ? t : r;
-            stage[i] = sorted[seg_first[r] + (i - seg_off[r])];
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    float best[KCAP];
-#pragma unroll
-    for (int j = 0; j < KCAP; j++) best[j] = j < pad ? -INFINITY : INFINITY;
-    int have = 0;
-    const f32x2 qxy = {q.x, q.y};
-    auto candidate = [&](const float4 p) {
-        const f32x2 dxy = qxy - f32x2{p.x, p.y};
-        const f32x2 sq = dxy * dxy;
-        const float dz = __fsub_rn(q.z, p.z);
-        const float d2 = __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));
-        if (d2 < best[KCAP - 1]) {
-            have++;
-#pragma unroll
-            for (int j = KCAP - 1; j >= 1; j--) best[j] = __builtin_amdgcn_fmed3f(best[j - 1], best[j], d2);
-            best[0] = fminf(best[0], d2);
-        }
-    };
-    auto scan_global = [&](uint32_t f, uint32_t l) {
-        uint32_t e = f;
-        for (; e + 4 <= l; e += 4) {
-            const float4 p0 = sorted[e], p1 = sorted[e + 1], p2 = sorted[e + 2], p3 = sorted[e + 3];
-            candidate(p0); candidate(p1); candidate(p2); candidate(p3);
-        }
-        for (; e < l; e++) candidate(sorted[e]);
-    };
-    {
-        const float eps = (float)(g.h * 1e-5), hf = (float)g.h;
-        const float ylo = (float)((double)g.mn[1] + (double)cy * g.h), zlo = (float)((double)g.mn[2] + (double)cz * g.h);
-        auto gap = [&](float v, float lo_face, int o) {
-            const float d = o == 0 ? 0.f : (o < 0 ? v - lo_face : lo_face + hf - v);
-            const float t = fmaxf(d - eps, 0.f);
-            return t * t;
-        };
-        auto scan_row = [&](int r) {
-            if (staged) {
-                const uint32_t shift = seg_off[r] - seg_first[r];   // (a point's place in `stage`: its place in `sorted` + shift, mod 2^32)
-                uint32_t e = first[r];
-                for (; e + 4 <= last[r]; e += 4) {   // (four LDS reads in flight)
-                    const float4 p0 = stage[e + shift], p1 = stage[e + shift + 1], p2 = stage[e + shift + 2], p3 = stage[e + shift + 3];
-                    candidate(p0); candidate(p1); candidate(p2); candidate(p3);
-                }
-                for (; e < last[r]; e++) candidate(stage[e + shift]);
-            } else {
-                scan_global(first[r], last[r]);
-            }
-        };
-        scan_row(4);
-        constexpr int order[8] = {1, 3, 5, 7, 0, 2, 6, 8};
-#pragma unroll
-        for (int o = 0; o < 8; o++) {
-            const int r = order[o];
-            if (gap(q.y, ylo, r % 3 - 1) + gap(q.z, zlo, r / 3 - 1) >= best[KCAP - 1]) continue;
-            scan_row(r);
-        }
-    }
-    const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
-    for (int ring = 1; ring <= maxring; ring++) {
-        if (ring > 1) {
-            const int xa = max(cx - ring, 0), xb = min(cx + ring, g.dim[0] - 1);
-            for (int dz = -ring; dz <= ring; dz++) {
-                const int zz = cz + dz;
-                if (zz < 0 || zz >= g.dim[2]) continue;
-                for (int dy = -ring; dy <= ring; dy++) {
-                    const int yy = cy + dy;
-                    if (yy < 0 || yy >= g.dim[1]) continue;
-                    const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
-                    uint32_t f, l;
-                    if (face) {
-                        row_range(xa, xb, yy, zz, f, l);
-                        scan_global(f, l);
-                    } else {
-                        if (cx - ring >= 0) { row_range(cx - ring, cx - ring, yy, zz, f, l); scan_global(f, l); }
-                        if (cx + ring < g.dim[0]) { row_range(cx + ring, cx + ring, yy, zz, f, l); scan_global(f, l); }
-                    }
-                }
-            }
-        }
-        if (have >= want) {
-            const double reach = (double)ring * g.h;
-            if ((double)best[KCAP - 1] < reach * reach * (1.0 - 1e-6)) break;
-        }
-    }
-    double sum = 0.0;
-#pragma unroll
-    for (int j = 1; j < KCAP; j++) {
-        if (j > pad && best[j] < INFINITY) sum += (double)sqrtf(best[j]);
-    }
-    dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
-}
+// (Round 4, built, measured and taken out again -- the commit before this comment's has the kernels, profiles/r04_sor_knn_staged.txt the figures:
+// the neighbourhood of 64 consecutive sorted points staged in LDS by the whole wave -- the nine runs of cells [ca - 1, cb + 1] shifted by the row
+// offsets, one round trip -- and every lane scanning its own three cells of each row there; before it, a wave per row of cells.  d_i bit-identical;
+// 43.0 us against 42.3 for a 36 k-point camera tile, the same at every cell size from 4 to 50 points per cell (a wave per row: 61-67 us).  The
+// kernel does not wait for its candidates: its time is the sorted insert -- 17 medians, run by the whole wave whenever ONE lane accepts, ~1400 of
+// ~4400 vector instructions per wave at one wave per SIMD -- and the second ring of the queries at the cloud's edge, which every wave has.)
 
 // ---- mean / variance, deterministic two-level sum ----
 __global__ void __launch_bounds__(BLK) stats_partial_kernel(const float *__restrict__ d, size_t n, double *__restrict__ partial) {
@@ -843,17 +677,7 @@ bool sor_dense_on_device(const DeviceSoA &src, int k, float *dev_dist, float *pa
         CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(grid_for(n)), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts, cursor,
                   sorted);
         const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
-        // r4: 64 queries per wave, their neighbourhood staged in LDS (knn_mean_dist_staged_kernel); CWIPC_SOR_STAGED=0: a lane per query
-        // reading the points where they lie, as in rounds 1-3; =2: the new kernel's structure without the staging (timing)
-        static const int staged_knob = []() { const char *e = getenv("CWIPC_SOR_STAGED"); return e ? atoi(e) : 1; }();
-        const bool by_chunks = staged_knob != 0;
-        const int no_stage = staged_knob == 2 ? 1 : 0;
-        const unsigned cgrid = (unsigned)((n + 63) / 64);
-        if (k + 1 <= 17 && by_chunks) {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_staged_kernel<17>, dim3(cgrid), dim3(64), 0, c.stream, meta, sorted, n, starts, counts, k, dev_dist, no_stage);
-        } else if (k + 1 <= 33 && by_chunks) {
-            CW_LAUNCH("sor_knn_mean_dist", knn_mean_dist_staged_kernel<33>, dim3(cgrid), dim3(64), 0, c.stream, meta, sorted, n, starts, counts, k, dev_dist, no_stage);
-        } else if (k + 1 <= 17) {
+        if (k + 1 <= 17) {
             CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
         } else if (k + 1 <= 33) {
             CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist);
