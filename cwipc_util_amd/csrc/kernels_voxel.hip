@@ -113,7 +113,6 @@ enum : uint32_t {
     ERR_FACE_TABLE = 32,     // a point lies beyond the threshold table (host reruns the exact variant)
     ERR_CELL_RANGE = 64,
     ERR_LIST_FULL = 128,
-    ERR_POOL = 256,          // the record pool is full (host regrows and reruns)
     ERR_LOCAL_LEAVES = 512,  // a workgroup met more leaves than its local leaf table holds: host reruns with global leaf ids in the hot loop
 };
 
@@ -123,7 +122,6 @@ enum {
     C_FALLBACK = 16,   // runs that found the workgroup table full and went to the global records one lane at a time
     C_MAXLOAD = 17,    // fullest workgroup table (entries)
     // 18: C_SCATTER (voxel_partition.inc)
-    C_SLOTS = 21,      // pool slots handed out beyond the workgroups' own (the general kernel's slow path)
     C_LEAVES = 20,     // octree leaves (or bricks of the plain grid) the pass has met = leaf grids in use
     C_FLUSHED = 19,    // table entries flushed by all workgroups = global record updates of the pass (the general variant counts them)
     C_SEQ = 31,        // number of published words (the host copy carries the pass's sequence number in the upper half of each 64-bit word)
@@ -153,12 +151,7 @@ struct VoxParams {
 
 struct VoxWork {
     unsigned long long *leaf_keys;   // [leaf id] 0 = none yet, else packed lattice coordinates | 1<<63 (ids are handed out in order of arrival)
-    uint32_t *slot_of;               // [leaf id][CELLS] the cell's newest record: pool slot + 1, 0 = the cell is empty
-    unsigned long long *pool;        // [pool_cap][8] records; word 7 >> 32 = the record that was the cell's before this one (slot + 1, 0 = none)
-    uint32_t pool_static;            // slots [0, pool_static): entry e of workgroup b of the accumulate kernel owns slot b * (table entries) + e and
-                                     //   writes it with plain stores; slots from pool_static on are handed out one by one (ctrl[C_SLOTS]) to the slow
-                                     //   path of the general kernel, which adds to them with atomics
-    uint32_t pool_cap;
+    unsigned long long *records;     // [leaf hash][CELLS][8]
     uint32_t *occupied;              // list of (leaf id << 19 | cell) of touched records
     uint32_t *ctrl;
     float *bboxes;                   // [nranges][6]
@@ -167,6 +160,8 @@ struct VoxWork {
     uint32_t *seg_count;             // [leaf hash][RANK_SEGS] occupied cells per bitmap slice (accumulated by K1's flush)
     unsigned long long *hash_keys;   // [4 x leaf grids] leaf -> id: open addressing on the packed coordinates ...
     uint32_t *hash_ids;              //   ... and the id + 1 of the entry's leaf (0: not published yet, ~0: no grid left)
+    uint32_t *dump_head;             // r4, fast accumulate kernel with FastParams::dump: per workgroup a DumpHead ...
+    uint32_t *dump_ent;              //   ... and room for the entries of its table, DUMP_ENTRY_WORDS words each (voxel_k1_fast.inc)
 };
 
 inline __host__ __device__ uint64_t mix64(uint64_t k) {
@@ -309,30 +304,9 @@ __device__ __forceinline__ uint32_t leaf_lookup(const VoxWork &W, uint32_t mask,
     return 0xffffffffu;
 }
 
-// The cell of voxel key = leaf id << 19 | cell  (a leaf's cells are CELLS words apart, not 2^19).
-__device__ __forceinline__ uint32_t *cell_slot(const VoxWork &W, uint32_t key) {
-    return W.slot_of + ((size_t)(key >> CELL_BITS) * CELLS + (key & ((1u << CELL_BITS) - 1)));
-}
-
-// What a cell has collected: the 64-bit words 0-6 of its records (voxel_k1_fast.inc, fast_flush_records) added up along the chain.
-// The cell and its records are left zeroed for the next call.  One lane.
-struct CellSums { unsigned long long w[7]; };
-__device__ __forceinline__ CellSums collect_cell(const VoxWork &W, uint32_t key) {
-    CellSums r;
-#pragma unroll
-    for (int i = 0; i < 7; i++) r.w[i] = 0ull;
-    uint32_t *cp = cell_slot(W, key);
-    uint32_t s = *cp;
-    if (s != 0u) *cp = 0u;
-    for (uint32_t guard = 0; s != 0u && s <= W.pool_cap && guard < (1u << 24); guard++) {
-        ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(W.pool + (size_t)(s - 1u) * RECORD_WORDS);
-        const ulonglong2 w01 = rec[0], w23 = rec[1], w45 = rec[2], w67 = rec[3];
-        r.w[0] += w01.x; r.w[1] += w01.y; r.w[2] += w23.x; r.w[3] += w23.y; r.w[4] += w45.x; r.w[5] += w45.y; r.w[6] += w67.x;
-        const ulonglong2 zero = {0ull, 0ull};
-        rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
-        s = (uint32_t)(w67.y >> 32);
-    }
-    return r;
+// Record of voxel key = leaf id << 19 | cell  (grids are CELLS records apart, not 2^19).
+__device__ __forceinline__ unsigned long long *record_ptr(const VoxWork &W, uint32_t key) {
+    return W.records + ((size_t)(key >> CELL_BITS) * CELLS + (key & ((1u << CELL_BITS) - 1))) * RECORD_WORDS;
 }
 
 // index into seg_count of the bitmap slice that holds a record's bit
@@ -453,16 +427,12 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
     if (__ballot(need_or) != 0ull) {
         if (need_or) atomicOr(&L.tile[slot], r.tile);
     }
-    // ---- table saturated (sparse or incoherent input): the runs go straight to records in global memory ----
-    // A cell's records form a chain (voxel_k1_fast.inc, fast_flush_records): workgroups put records of their OWN in front, which
-    // they write with plain stores and nobody may add to.  The runs that come this way add, with atomics, to a record of the
-    // pool's second part (slots from pool_static on, handed out here): the one at the head of the cell's chain if that is such a
-    // record, else a new one put in front.  Whoever finds the cell empty has touched it first.
+    // ---- table saturated (sparse or incoherent input): the runs go straight to the global records ----
     const unsigned long long failed = __ballot(active && pending);
     if (__builtin_expect(failed != 0ull, 0)) {
         const bool mine = active && pending;
         const int lane = threadIdx.x & 63;
-        // the cell of this lane's run (global leaf id * CELLS + cell), ~0 if it has none
+        // the record of this lane's run (global leaf id * CELLS + cell), ~0 if it has none
         uint32_t rec = 0xffffffffu;
         if (mine) {
             atomicAdd(&L.nfallback, 1u);
@@ -473,81 +443,18 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
             }
             if (gid != 0xffffffffu) rec = gid * (uint32_t)CELLS + (r.key & ((1u << CELL_BITS) - 1));
         }
-        // the record the run adds to (pool slot; ~0: none), and whether the run is the cell's first
-        uint32_t gslot = 0xffffffffu;
-        bool first_touch = false;
-        {
-            bool looking = rec != 0xffffffffu;
-#pragma unroll 1
-            for (int round = 0; round < 64; round++) {
-                if (__ballot(looking) == 0ull) break;
-                uint32_t head = 0;
-                if (looking) {
-                    head = __hip_atomic_load(&W.slot_of[rec], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (head > W.pool_static) { gslot = head - 1u; looking = false; }
-                }
-                // new slots for the lanes still looking: one bump of the counter per wave and round (many lanes on one counter
-                // serialise at the memory side)
-                const unsigned long long want = __ballot(looking);
-                if (want == 0ull) break;
-                uint32_t base = 0;
-                if (lane == __ffsll((long long)want) - 1) base = atomicAdd(&W.ctrl[C_SLOTS], (uint32_t)__popcll(want));
-                base = (uint32_t)__shfl((int)base, __ffsll((long long)want) - 1, 64);
-                if (looking) {
-                    const unsigned long long got = (unsigned long long)W.pool_static + base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-                    if (got >= (unsigned long long)W.pool_cap) {
-                        atomicOr(&W.ctrl[C_ERR], ERR_POOL);
-                        looking = false;
-                    } else {
-                        const uint32_t d = (uint32_t)got;
-                        unsigned long long *link = &W.pool[(size_t)d * RECORD_WORDS + 7];
-                        if (head != 0u) __hip_atomic_store(link, (unsigned long long)head << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t seen = atomicCAS(&W.slot_of[rec], head, d + 1u);
-                        if (seen == head) {
-                            gslot = d; first_touch = head == 0u; looking = false;
-                        } else if (head != 0u) {
-                            // the chain got a new head meanwhile: the slot stays unused (and zero, as the pool has to be left), look again
-                            __hip_atomic_store(link, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-            }
-            if (looking) atomicOr(&W.ctrl[C_ERR], ERR_POOL);   // (64 lost races in a row: not seen; the pass is run again)
-        }
-        if (first_touch) {
-            const uint32_t gid = rec / (uint32_t)CELLS;
-            const uint32_t key = (gid << CELL_BITS) | (rec - gid * (uint32_t)CELLS);
-            mark_occupied(W, key);
-            atomicAdd(&W.seg_count[slice_of(key)], 1u);
-        }
-        // cells touched for the first time: counted (and listed) with one atomic per wave
-        {
-            const unsigned long long news = __ballot(first_touch);
-            if (news != 0ull) {
-                const uint32_t nnew = (uint32_t)__popcll(news);
-                uint32_t base = 0;
-                if (lane == __ffsll((long long)news) - 1) base = atomicAdd(&W.ctrl[C_COUNT], nnew);
-                if (P.want_list) {
-                    base = (uint32_t)__shfl((int)base, __ffsll((long long)news) - 1, 64);
-                    if (first_touch) {
-                        const uint32_t gid = rec / (uint32_t)CELLS;
-                        const uint32_t idx = base + (uint32_t)__popcll(news & ((1ull << lane) - 1ull));
-                        if (idx < P.list_cap) W.occupied[idx] = (gid << CELL_BITS) | (rec - gid * (uint32_t)CELLS);
-                        else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
-                    }
-                }
-            }
-        }
         // Eight lanes per run update its 64-byte record with one instruction (one cache-line operation
         // in L2 instead of six: incoherent clouds are bound by exactly that), eight runs per instruction.
 #pragma unroll 1
         for (int b = 0; b < 8; b++) {
             if (((failed >> (8 * b)) & 0xffull) == 0ull) continue;
             const int src = 8 * b + (lane >> 3), sub = lane & 7;
-            const uint32_t s_slot = (uint32_t)__shfl((int)gslot, src, 64);
+            const uint32_t s_rec = (uint32_t)__shfl((int)rec, src, 64);
             const uint32_t s_qx = (uint32_t)__shfl((int)r.qx, src, 64), s_qy = (uint32_t)__shfl((int)r.qy, src, 64), s_qz = (uint32_t)__shfl((int)r.qz, src, 64);
             const uint32_t s_cr = (uint32_t)__shfl((int)r.cr, src, 64), s_gb = (uint32_t)__shfl((int)r.gb, src, 64), s_tile = (uint32_t)__shfl((int)r.tile, src, 64);
-            if (s_slot != 0xffffffffu && sub < 7) {
+            bool first = false;
+            uint32_t s_key = 0;
+            if (s_rec != 0xffffffffu && sub < 7) {
                 const uint32_t cnt = s_cr >> 16;
                 unsigned long long val;
                 switch (sub) {
@@ -565,7 +472,28 @@ __device__ __forceinline__ void lds_insert(LdsTable &L, const VoxWork &W, const 
                           ((unsigned long long)((s_tile >> 6) & 1u) << 32) | ((unsigned long long)((s_tile >> 7) & 1u) << 48);
                     break;
                 }
-                if (val != 0ull) atomicAdd(&W.pool[(size_t)s_slot * RECORD_WORDS + sub], val);
+                const unsigned long long old = atomicAdd(&W.records[(size_t)s_rec * RECORD_WORDS + sub], val);
+                if (sub == 3 && (old >> 32) == 0) {
+                    first = true;
+                    s_key = ((s_rec / (uint32_t)CELLS) << CELL_BITS) | (s_rec % (uint32_t)CELLS);
+                    mark_occupied(W, s_key);
+                    atomicAdd(&W.seg_count[slice_of(s_key)], 1u);
+                }
+            }
+            // records touched for the first time: counted (and listed) with one atomic per instruction
+            const unsigned long long news = __ballot(first);
+            if (news != 0ull) {
+                const uint32_t nnew = (uint32_t)__popcll(news);
+                uint32_t base = 0;
+                if (lane == __ffsll((long long)news) - 1) base = atomicAdd(&W.ctrl[C_COUNT], nnew);
+                if (P.want_list) {
+                    base = (uint32_t)__shfl((int)base, __ffsll((long long)news) - 1, 64);
+                    if (first) {
+                        const uint32_t idx = base + (uint32_t)__popcll(news & ((1ull << lane) - 1ull));
+                        if (idx < P.list_cap) W.occupied[idx] = s_key;
+                        else atomicOr(&W.ctrl[C_ERR], ERR_LIST_FULL);
+                    }
+                }
             }
         }
     }
@@ -1129,9 +1057,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
         }
     }
 
-    // ---- flush: 8 lanes per table entry -- seven store the words of the entry's own record (slot blockIdx.x * LTAB + entry of the
-    // pool: voxel_k1_fast.inc, fast_flush_records), the eighth puts the slot into the entry's cell and gets back what was there ----
-    // All requests of a lane are issued before the first result is looked at, so that their round
+    // ---- flush: 8 lanes per table entry update one 64-byte record with returning adds ----
+    // All adds of a lane are issued before the first result is looked at, so that their round
     // trips overlap (this is the serial tail of the kernel: nothing else is in flight any more).
     __syncthreads();
     if (P.local_leaves) {
@@ -1146,9 +1073,8 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
     const int sub = threadIdx.x & 7;
     constexpr int FLUSH_ITERS = LTAB / (K1_THREADS / 8);
     uint32_t fkey[FLUSH_ITERS];
-    uint32_t fold[FLUSH_ITERS];   // lanes with sub == 7: what the entry's cell held before
+    unsigned long long fold[FLUSH_ITERS];
     uint32_t used = 0;   // entries in use (lanes with sub == 0 count them)
-    const uint32_t slot_base = blockIdx.x * (uint32_t)LTAB;
 #pragma unroll
     for (int it = 0; it < FLUSH_ITERS; it++) {
         const int e = (threadIdx.x >> 3) + it * (K1_THREADS / 8);
@@ -1159,7 +1085,7 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             k = gid == 0xffffffffu ? KEY_EMPTY : ((gid << CELL_BITS) | (k & ((1u << CELL_BITS) - 1)));
         }
         fkey[it] = k;
-        fold[it] = 0u;
+        fold[it] = ~0ull;
         if (k == KEY_EMPTY) continue;
         used += sub == 0 ? 1u : 0u;
         const uint32_t t = L.tile[e];
@@ -1182,25 +1108,16 @@ __global__ void __launch_bounds__(K1_THREADS) voxel_accumulate_kernel(K1Params P
             break;
         default: val = 0; break;
         }
-        if (sub == 7) {
-            fold[it] = atomicExch(cell_slot(W, k), slot_base + (uint32_t)e + 1u);
-            mark_occupied(W, k);
-        } else if (val != 0ull) {
-            W.pool[(size_t)(slot_base + (uint32_t)e) * RECORD_WORDS + sub] = val;   // (the pool is zero where nobody has written)
-        }
+        fold[it] = atomicAdd(&record_ptr(W, k)[sub], val);
     }
 #pragma unroll
     for (int it = 0; it < FLUSH_ITERS; it++) {
         const uint32_t k = fkey[it];
-        if (sub != 7 || k == KEY_EMPTY) continue;
-        if (fold[it] != 0u) {
-            // the cell had a record already (another workgroup's, or one of the slow path): this entry's goes in front of it
-            const int e = (threadIdx.x >> 3) + it * (K1_THREADS / 8);
-            W.pool[(size_t)(slot_base + (uint32_t)e) * RECORD_WORDS + 7] = (unsigned long long)fold[it] << 32;
-        } else {
-            // first touch of this cell in this call: list it, count it in its bitmap slice
+        if (sub == 3 && k != KEY_EMPTY && (fold[it] >> 32) == 0) {
+            // first touch of this record in this call: list it, set its bit, count it in its bitmap slice
             const uint32_t at = atomicAdd(&L.nfresh, 1u);
             if (P.want_list) L.fresh[at] = k;
+            mark_occupied(W, k);
             const uint32_t sl = slice_of(k);
             uint32_t hs = (sl * 0x9E3779B1u) >> 24;   // HIST = 2^8
             bool counted = false;
@@ -1517,17 +1434,42 @@ __global__ void __launch_bounds__(256) make_sort_keys_kernel(VoxParams P, VoxWor
 // ---------------------------------------------------------------------------
 // K4: emit in output order and clean the records
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W, unsigned long long lp, uint32_t key, uint32_t r,
-                                            float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow);
-
 __global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWork W, uint32_t m, const uint32_t *__restrict__ sorted_keys,
                                                             float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
                                                             uint32_t *__restrict__ ow, int emit) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
     const uint32_t key = emit ? sorted_keys[r] : W.occupied[r];
-    if (emit) emit_record(P, W, W.leaf_keys[key >> CELL_BITS], key, r, ox, oy, oz, ow);
-    else (void)collect_cell(W, key);   // (leaves cell and records zeroed)
+    ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(record_ptr(W, key));
+    if (emit) {
+        const ulonglong2 w01 = rec[0], w23 = rec[1], w45 = rec[2], w67 = rec[3];
+        const uint32_t cell = key & ((1u << CELL_BITS) - 1), leaf_id = key >> CELL_BITS;
+        const int c[3] = {(int)(cell % GRID_DIM), (int)((cell / GRID_DIM) % GRID_DIM), (int)(cell / (GRID_DIM * GRID_DIM))};
+        const unsigned long long lp = W.leaf_keys[leaf_id];
+        double vox[3];
+        for (int a = 0; a < 3; a++) vox[a] = (double)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2);
+        const unsigned long long cr = w23.y, gb = w45.x;
+        const uint32_t cnt = (uint32_t)(cr >> 32);
+        const double scale = P.q_unit / (double)cnt;
+        // mean = (voxel + mean position inside the voxel) / inv_leaf; one rounding to fp32 at the end
+        ox[r] = (float)(vox[0] * P.vox_unit + (double)(long long)w01.x * scale);
+        oy[r] = (float)(vox[1] * P.vox_unit + (double)(long long)w01.y * scale);
+        oz[r] = (float)(vox[2] * P.vox_unit + (double)(long long)w23.x * scale);
+        // pcl AccumulatorRGBA: float sums (exact integers here) / n, truncated
+        const float fn = (float)cnt;
+        const uint32_t rr = (uint32_t)__fdiv_rn((float)(uint32_t)(cr & 0xffffffffu), fn);
+        const uint32_t gg = (uint32_t)__fdiv_rn((float)(uint32_t)(gb >> 32), fn);
+        const uint32_t bb = (uint32_t)__fdiv_rn((float)(uint32_t)(gb & 0xffffffffu), fn);
+        // tile: bits 0-3 / 4-7 as contribution counters, plus the OR word of the slow path
+        uint32_t tile = (uint32_t)w67.y & 0xffu;
+        for (int b = 0; b < 4; b++) {
+            if ((w45.y >> (16 * b)) & 0xffffull) tile |= 1u << b;
+            if ((w67.x >> (16 * b)) & 0xffffull) tile |= 16u << b;
+        }
+        ow[r] = (rr & 0xffu) | ((gg & 0xffu) << 8) | ((bb & 0xffu) << 16) | (tile << 24);
+    }
+    const ulonglong2 zero = {0ull, 0ull};
+    rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
     const uint32_t bit_cell = key & ((1u << CELL_BITS) - 1);
     atomicAnd(&W.bitmaps[(size_t)(key >> CELL_BITS) * BITWORDS + (bit_cell >> 5)], ~(1u << (bit_cell & 31u)));
 }
@@ -1538,30 +1480,31 @@ __global__ void __launch_bounds__(256) emit_and_clean_kernel(VoxParams P, VoxWor
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void emit_record(const VoxParams &P, const VoxWork &W, unsigned long long lp, uint32_t key, uint32_t r,
                                             float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz, uint32_t *__restrict__ ow) {
-    const CellSums sums = collect_cell(W, key);   // (leaves cell and records zeroed)
+    ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(record_ptr(W, key));
+    const ulonglong2 w01 = rec[0], w23 = rec[1], w45 = rec[2], w67 = rec[3];
     const uint32_t cell = key & ((1u << CELL_BITS) - 1);
     const int c[3] = {(int)(cell % GRID_DIM), (int)((cell / GRID_DIM) % GRID_DIM), (int)(cell / (GRID_DIM * GRID_DIM))};
     double vox[3];
     for (int a = 0; a < 3; a++) vox[a] = (double)(c[a] + P.ib[a] + 64 * unpack_leaf(lp, a) - 2);
-    const unsigned long long cr = sums.w[3], gb = sums.w[4];
+    const unsigned long long cr = w23.y, gb = w45.x;
     const uint32_t cnt = (uint32_t)(cr >> 32);
     // mean = voxel origin + mean offset (f64, one division), one rounding to fp32 at the end
     const double scale = P.q_unit / (double)cnt;
-    ox[r] = (float)(vox[0] * P.vox_unit + (double)(long long)sums.w[0] * scale);
-    oy[r] = (float)(vox[1] * P.vox_unit + (double)(long long)sums.w[1] * scale);
-    oz[r] = (float)(vox[2] * P.vox_unit + (double)(long long)sums.w[2] * scale);
-    // pcl AccumulatorRGBA: float sums (exact integers here) / n, truncated
+    ox[r] = (float)(vox[0] * P.vox_unit + (double)(long long)w01.x * scale);
+    oy[r] = (float)(vox[1] * P.vox_unit + (double)(long long)w01.y * scale);
+    oz[r] = (float)(vox[2] * P.vox_unit + (double)(long long)w23.x * scale);
     const float fn = (float)cnt;
     const uint32_t rr = (uint32_t)__fdiv_rn((float)(uint32_t)(cr & 0xffffffffu), fn);
     const uint32_t gg = (uint32_t)__fdiv_rn((float)(uint32_t)(gb >> 32), fn);
     const uint32_t bb = (uint32_t)__fdiv_rn((float)(uint32_t)(gb & 0xffffffffu), fn);
-    // tile: bits 0-3 / 4-7 as contribution counters
-    uint32_t tile = 0;
+    uint32_t tile = (uint32_t)w67.y & 0xffu;
     for (int b = 0; b < 4; b++) {
-        if ((sums.w[5] >> (16 * b)) & 0xffffull) tile |= 1u << b;
-        if ((sums.w[6] >> (16 * b)) & 0xffffull) tile |= 16u << b;
+        if ((w45.y >> (16 * b)) & 0xffffull) tile |= 1u << b;
+        if ((w67.x >> (16 * b)) & 0xffffull) tile |= 16u << b;
     }
     ow[r] = (rr & 0xffu) | ((gg & 0xffu) << 8) | ((bb & 0xffu) << 16) | (tile << 24);
+    const ulonglong2 zero = {0ull, 0ull};
+    rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
 }
 
 // RANK_SEGS workgroups per leaf, each owning a contiguous slice of the leaf's bitmap: output base
@@ -1867,7 +1810,9 @@ __global__ void __launch_bounds__(RANK_THREADS) clean_by_bitmap_kernel(VoxWork W
         while (bits) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            (void)collect_cell(W, (p << CELL_BITS) | (uint32_t)(w * 32 + b));
+            ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(record_ptr(W, (p << CELL_BITS) | (uint32_t)(w * 32 + b)));
+            const ulonglong2 zero = {0ull, 0ull};
+            rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
         }
     }
 }
@@ -1941,16 +1886,15 @@ struct Workspace {
     unsigned long long *leaf_keys = nullptr;
     unsigned long long *hash_keys = nullptr;
     uint32_t *hash_ids = nullptr;
-    uint32_t *slot_of = nullptr;       // [leaf_cap][CELLS]: a cell's newest record (VoxWork::slot_of)
-    unsigned long long *pool = nullptr;   // pool_cap records of 64 bytes (VoxWork::pool), left zeroed by the emit kernels
-    size_t pool_cap = 0;
-    size_t pool_spare = 1 << 16;       // slots beyond the accumulate kernel's workgroups' own: for the general kernel's slow path (x 4 on ERR_POOL)
+    unsigned long long *records = nullptr;
     uint32_t *occupied = nullptr;
     uint32_t *order = nullptr;         // records in output order (finalize pass), list_cap entries
     uint32_t *gbits = nullptr;         // plain grid: bitmap over the VoxelGrid index space, its per-word and per-block prefixes
     uint32_t *gprefix = nullptr, *gblock = nullptr;
     size_t gwords_cap = 0;
     float *bboxes = nullptr;           // [2][bbox_cap][6]: the ranges' boxes the replay kernel reads; behind them room for boxes nobody reads
+    uint32_t *dump_head = nullptr, *dump_ent = nullptr;   // what the fast accumulate kernel leaves for the merge kernel (r4) ...
+    size_t dump_blocks = 0, dump_entries = 0;             //   ... for this many workgroups of this many table entries
     float *part = nullptr;             // partition pass: the cloud moved into spatial buckets, four planes of part_stride elements
     size_t part_stride = 0;
     uint32_t *part_hist = nullptr;     //   ... and its PART_BUCKETS bucket counts / cursors
@@ -1967,15 +1911,16 @@ struct Workspace {
         if (part_hist) (void)hipFree(part_hist);
         part = nullptr; part_hist = nullptr; part_stride = 0;
     }
-    void drop_pool() {
-        if (pool) { (void)hipFree(pool); g_workspace_bytes -= pool_cap * RECORD_WORDS * 8; }
-        pool = nullptr; pool_cap = 0;
+    void drop_dump_buffers() {
+        if (dump_head) (void)hipFree(dump_head);
+        if (dump_ent) { (void)hipFree(dump_ent); g_workspace_bytes -= dump_blocks * dump_entries * DUMP_ENTRY_WORDS * 4; }
+        dump_head = dump_ent = nullptr; dump_blocks = dump_entries = 0;
     }
     void release() {
         // also runs at thread exit, when the runtime may be gone: errors ignored
-        drop_pool();
+        drop_dump_buffers();
         if (head) (void)hipFree(head);
-        if (slot_of) (void)hipFree(slot_of);
+        if (records) (void)hipFree(records);
         if (occupied) (void)hipFree(occupied);
         if (order) (void)hipFree(order);
         if (gbits) (void)hipFree(gbits);
@@ -1991,7 +1936,7 @@ struct Workspace {
         g_workspace_bytes -= grid_bytes;
         grid_bytes = 0;
         bitmaps = nullptr; seg_count = nullptr; head = nullptr; head_bytes = 0;
-        leaf_keys = nullptr; slot_of = nullptr; occupied = nullptr; order = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
+        leaf_keys = nullptr; records = nullptr; occupied = nullptr; order = nullptr; bboxes = nullptr; ctrl = nullptr; faces = nullptr;
         leaf_cap = 0; list_cap = 0; bbox_cap = 0;
         faces_valid = false;
     }
@@ -2066,7 +2011,7 @@ struct StreamOfWorkspace {
     }
 };
 
-constexpr size_t GRID_BYTES = (size_t)CELLS * sizeof(uint32_t);   // 1.26 MB per leaf: 4 bytes per cell (rounds 1-3: a 64-byte record per cell, 20.1 MB)
+constexpr size_t GRID_BYTES = (size_t)CELLS * RECORD_WORDS * 8;   // 20.1 MB per leaf grid
 constexpr size_t HEAD_CTRL_BYTES = 256;                           // C_WORDS words, padded
 
 bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nranges, hipStream_t s) {
@@ -2089,10 +2034,10 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
     }
     if (ws.leaf_cap < leaf_cap) {
         if (ws.head) (void)hipFree(ws.head);
-        if (ws.slot_of) (void)hipFree(ws.slot_of);
+        if (ws.records) (void)hipFree(ws.records);
         if (ws.bitmaps) (void)hipFree(ws.bitmaps);
         ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr;
-        ws.slot_of = nullptr; ws.bitmaps = nullptr; ws.leaf_cap = 0;
+        ws.records = nullptr; ws.bitmaps = nullptr; ws.leaf_cap = 0;
         ws.head_bytes = HEAD_CTRL_BYTES + (size_t)leaf_cap * 8 + (size_t)leaf_cap * RANK_SEGS * sizeof(uint32_t) + (size_t)leaf_cap * 4 * (8 + 4);
         ws.head_bytes = (ws.head_bytes + 255) & ~(size_t)255;
         CW_HIP_TRY(hipMalloc(&ws.head, 2 * ws.head_bytes));
@@ -2100,8 +2045,8 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         ws.parity = 0;
         CW_HIP_TRY(hipMalloc((void **)&ws.bitmaps, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t)));
         CW_HIP_TRY(hipMemsetAsync(ws.bitmaps, 0, (size_t)leaf_cap * BITWORDS * sizeof(uint32_t), s));
-        CW_HIP_TRY(hipMalloc((void **)&ws.slot_of, (size_t)leaf_cap * GRID_BYTES));
-        CW_HIP_TRY(hipMemsetAsync(ws.slot_of, 0, (size_t)leaf_cap * GRID_BYTES, s));   // once; the emit kernels keep it clean afterwards
+        CW_HIP_TRY(hipMalloc((void **)&ws.records, (size_t)leaf_cap * GRID_BYTES));
+        CW_HIP_TRY(hipMemsetAsync(ws.records, 0, (size_t)leaf_cap * GRID_BYTES, s));   // once; K4 keeps it clean afterwards
         ws.leaf_cap = leaf_cap;
         g_workspace_bytes -= ws.grid_bytes;
         ws.grid_bytes = (size_t)leaf_cap * (GRID_BYTES + BITWORDS * sizeof(uint32_t)) + 2 * ws.head_bytes;
@@ -2126,19 +2071,6 @@ bool ensure_workspace(Workspace &ws, size_t n, uint32_t leaf_cap, uint32_t nrang
         CW_HIP_TRY(hipHostMalloc((void **)&ws.host_words, 2 * C_WORDS * sizeof(uint32_t), hipHostMallocDefault));
         memset(ws.host_words, 0, 2 * C_WORDS * sizeof(uint32_t));
     }
-    return true;
-}
-
-// Room for `slots` records.  Only between passes: the pool is all zero then (the emit kernels leave it so), so a bigger one
-// need not take anything over.
-bool ensure_pool(Workspace &ws, size_t slots, hipStream_t s) {
-    if (ws.pool_cap >= slots) return true;
-    ws.drop_pool();
-    if (slots > 0xfffffff0u) return false;
-    CW_HIP_TRY(hipMalloc((void **)&ws.pool, slots * RECORD_WORDS * 8));
-    CW_HIP_TRY(hipMemsetAsync(ws.pool, 0, slots * RECORD_WORDS * 8, s));
-    ws.pool_cap = slots;
-    g_workspace_bytes += slots * RECORD_WORDS * 8;
     return true;
 }
 
@@ -2305,7 +2237,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             if (p->leaf_split) ws.last_m = 0; else ws.last_m_grid = 0;
             ws.streak = 0;
             if (p->err & (ERR_FAST_PATH | ERR_CELL_RANGE)) ws.no_fast = true;
-            VoxWork W{ws.leaf_keys, ws.slot_of, ws.pool, 0u, (uint32_t)ws.pool_cap, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
+            VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids, ws.dump_head, ws.dump_ent};
             CW_LAUNCH("clean_by_bitmap", clean_by_bitmap_kernel, dim3(ws.leaf_cap * RANK_SEGS), dim3(RANK_THREADS), 0, c.stream, W);
             if (!c.sync()) { hip_failed(hipGetLastError(), "voxel workspace clean-up", __FILE__, __LINE__); return nullptr; }
         }
@@ -2449,15 +2381,15 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         // (this thread's last pass on the workspace may have its finalize kernel in flight still)
         if (!c.sync()) return nullptr;
         if (ws.head) (void)hipFree(ws.head);
-        if (ws.slot_of) (void)hipFree(ws.slot_of);
+        if (ws.records) (void)hipFree(ws.records);
         if (ws.bitmaps) (void)hipFree(ws.bitmaps);
-        ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr; ws.slot_of = nullptr; ws.bitmaps = nullptr;
+        ws.head = nullptr; ws.ctrl = nullptr; ws.leaf_keys = nullptr; ws.seg_count = nullptr; ws.records = nullptr; ws.bitmaps = nullptr;
         g_workspace_bytes -= ws.grid_bytes;
         ws.grid_bytes = 0;
         ws.leaf_cap = 0;
     }
-    // 16 leaves = 20 MB to begin with (a camera tile at 1 cm has 2 to 4 leaves, a person-sized cloud 12 to 16); x4 when a cloud has more
-    uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : (ws.shrink_to ? ws.shrink_to : 16);
+    // 4 grids = 80 MB to begin with (a camera tile at 1 cm has 2 to 4 leaves, a person-sized cloud 12 to 16); x4 when a cloud has more
+    uint32_t leaf_cap = ws.leaf_cap ? ws.leaf_cap : (ws.shrink_to ? ws.shrink_to : 4);
     if (ws.shrink_to) ws.roomy = 0;
     ws.shrink_to = 0;
     int mode = leaf_split ? 1 : 0;
@@ -2476,7 +2408,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         ws.seg_count = (uint32_t *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8);
         ws.hash_keys = (unsigned long long *)(head + HEAD_CTRL_BYTES + (size_t)ws.leaf_cap * 8 + (size_t)ws.leaf_cap * RANK_SEGS * sizeof(uint32_t));
         ws.hash_ids = (uint32_t *)((char *)ws.hash_keys + (size_t)ws.leaf_cap * 4 * 8);
-        VoxWork W{ws.leaf_keys, ws.slot_of, ws.pool, 0u, (uint32_t)ws.pool_cap, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids};
+        VoxWork W{ws.leaf_keys, ws.records, ws.occupied, ws.ctrl, ws.bboxes, ws.faces, ws.bitmaps, ws.seg_count, ws.hash_keys, ws.hash_ids, ws.dump_head, ws.dump_ent};
         bool ok = true;
         if (!ws.head_clean[blk]) ok = hipMemsetAsync(head, 0, ws.head_bytes, c.stream) == hipSuccess;
         ws.head_clean[blk] = false;
@@ -2530,12 +2462,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             Wk.bboxes = ws.bboxes + (size_t)ws.bbox_cap * 6;   // the boxes of the moved points: nobody reads them
         }
         used_fast = fast;
-        if (!fast) {
-            // every entry of every workgroup's table has a record of its own in the pool; the slow path takes slots behind them
-            if (!ensure_pool(ws, (size_t)nblocks * LTAB + ws.pool_spare, c.stream)) return nullptr;
-            W.pool = ws.pool; W.pool_cap = (uint32_t)ws.pool_cap; W.pool_static = (uint32_t)((size_t)nblocks * LTAB);
-            Wk.pool = W.pool; Wk.pool_cap = W.pool_cap; Wk.pool_static = W.pool_static;
-        }
         uint32_t fast_blocks = 0, fast_per_wg = 0;
         if (fast) {
             FastParams F;
@@ -2556,16 +2482,42 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
+            // r4: the accumulate kernel may leave its tables' entries in the workspace, for a kernel of small workgroups right behind it to
+            // take to the records (voxel_k1_fast.inc, fast_dump / voxel_merge_kernel): the accumulate kernel alone 53.4 -> 48.1 us, the merge
+            // kernel 20 us alone -- a loss for a call that is waited for (64.6 -> 78.7 us with count()), possibly a gain in a stream of calls,
+            // where the merge workgroups (one wave per SIMD, 64 registers, 19 KB of LDS) run beside the NEXT call's accumulate kernel.
+            // CWIPC_K1_DUMP: 0 never, 1 always, 2 when this call is going to return with its kernels in flight (a stream); default 0
+            // until the stream figure says otherwise (profiles/r04_k1_dump_merge.txt)
+            static const int dump_mode = []() { const char *e = getenv("CWIPC_K1_DUMP"); return e ? atoi(e) : 0; }();
+            static const bool defer_allowed = []() { const char *e = getenv("CWIPC_DEFER"); return !e || atoi(e) != 0; }();
+            const bool will_defer = deferred && defer_allowed && attempt == 0 && ws.streak >= 2 && !profiling_enabled() &&
+                                    (leaf_split ? ws.last_m > 0 : (ws.last_m_grid > 0 && ws.gwords_cap > 0));
+            const bool dump_knob = dump_mode == 1 || (dump_mode == 2 && will_defer);
             const size_t table_entries = pair ? (size_t)PAIR_LTAB : (size_t)LTAB;
-            // every entry of every workgroup's table has a record of its own in the pool (fast_flush_records)
-            if (!ensure_pool(ws, (size_t)fast_blocks * table_entries + ws.pool_spare, c.stream)) return nullptr;
-            W.pool = ws.pool; W.pool_cap = (uint32_t)ws.pool_cap; W.pool_static = (uint32_t)((size_t)fast_blocks * table_entries);
+            bool dump = dump_knob;
+            if (dump && (ws.dump_blocks < fast_blocks || ws.dump_entries != table_entries)) {
+                ws.drop_dump_buffers();
+                const size_t blocks_cap = std::max<size_t>(fast_blocks, 256);
+                if (hipMalloc((void **)&ws.dump_head, blocks_cap * sizeof(DumpHead)) != hipSuccess ||
+                    hipMalloc((void **)&ws.dump_ent, blocks_cap * table_entries * DUMP_ENTRY_WORDS * 4) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (ws.dump_head) (void)hipFree(ws.dump_head);
+                    ws.dump_head = ws.dump_ent = nullptr;
+                    dump = false;   // no room for the tables: this pass updates the records from the accumulate kernel
+                } else {
+                    ws.dump_blocks = blocks_cap; ws.dump_entries = table_entries;
+                    g_workspace_bytes += blocks_cap * table_entries * DUMP_ENTRY_WORDS * 4;
+                }
+            }
+            W.dump_head = ws.dump_head; W.dump_ent = ws.dump_ent;
+            F.dump = dump ? 1u : 0u;
 #ifdef CWIPC_DEBUG_KNOBS
             static const uint32_t fast_dbg = []() { const char *e = getenv("CWIPC_FAST_DBG"); return e ? (uint32_t)atoi(e) : 0u; }();
             if (fast_dbg) cwipc_log(CWIPC_LOG_LEVEL_WARNING, "cwipc_downsample", "CWIPC_FAST_DBG is set: results are WRONG (timing experiments only)");
             F.dbg = fast_dbg;
 #endif
-            const size_t lds_pair = sizeof(PairTable), lds_one = sizeof(FastTable);
+            // (a workgroup that leaves its table needs the LDS up to the list of entries in use only: 105 instead of 151 KB)
+            const size_t lds_pair = dump ? PairTable::DUMP_LDS_BYTES : sizeof(PairTable), lds_one = dump ? FastTable::DUMP_LDS_BYTES : sizeof(FastTable);
             if (pair && mode == 0) {
                 CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<0, PAIR_THREADS, PAIR_LTAB>), dim3(fast_blocks), dim3(PAIR_THREADS), lds_pair, c.stream, F,
                           src.x(), src.y(), src.z(), src.rgbt(), W);
@@ -2578,6 +2530,11 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             } else {
                 CW_LAUNCH("voxel_accumulate", (voxel_accumulate_fast_kernel<1, K1_THREADS, LTAB>), dim3(fast_blocks), dim3(K1_THREADS), lds_one, c.stream, F, src.x(),
                           src.y(), src.z(), src.rgbt(), W);
+            }
+            if (dump && mode == 0) {
+                CW_LAUNCH("voxel_merge", voxel_merge_kernel<0>, dim3(fast_blocks), dim3(MERGE_THREADS), 0, c.stream, F, (uint32_t)table_entries, W);
+            } else if (dump) {
+                CW_LAUNCH("voxel_merge", voxel_merge_kernel<1>, dim3(fast_blocks), dim3(MERGE_THREADS), 0, c.stream, F, (uint32_t)table_entries, W);
             }
         } else if (mode == 0) {
             CW_LAUNCH("voxel_accumulate_general", voxel_accumulate_kernel<0>, dim3(nblocks), dim3(K1_THREADS), sizeof(LdsTable), c.stream, K, kx, ky, kz, kw, Wk);
@@ -2887,22 +2844,14 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         if (error_code) *error_code = (int)err;
         if (!ok) { hip_failed(hipGetLastError(), "voxel emit", __FILE__, __LINE__); return nullptr; }
 
-        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES | ERR_LIST_FULL | ERR_FAST_PATH | ERR_POOL | (used_fast ? ERR_CELL_RANGE : 0u);
+        const uint32_t retryable = ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES | ERR_LIST_FULL | ERR_FAST_PATH | (used_fast ? ERR_CELL_RANGE : 0u);
         if (used_fast && (err & (ERR_FAST_PATH | ERR_CELL_RANGE)) && !(err & ~retryable)) {
             // not a cloud for the fast variant (its table, its key or its slabs): the touched records were cleaned above
             ws.no_fast = true;
             continue;
         }
-        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES | ERR_POOL)) && !(err & ~retryable)) {
+        if ((err & (ERR_LEAVES | ERR_FACE_TABLE | ERR_LOCAL_LEAVES)) && !(err & ~retryable)) {
             if (err & ERR_LOCAL_LEAVES) local_leaves = false;   // a workgroup spans more than 64 leaves: global ids in the hot loop
-            if (err & ERR_POOL) {
-                // the general kernel's slow path (a cloud in no order whose voxels the workgroup tables could not hold) ran out of records
-                if (ws.pool_spare * 4 * RECORD_WORDS * 8 > ((size_t)64 << 30)) {
-                    cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed: the cloud needs more records than fit in device memory");
-                    return nullptr;
-                }
-                ws.pool_spare *= 4;
-            }
             // the touched records were cleaned above; change what was too small and run again
             if (err & ERR_FACE_TABLE) mode = 2;   // points beyond the threshold table: per-point f64 variant
             if (err & ERR_LEAVES) {
@@ -2921,7 +2870,6 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             if (err & (ERR_DEPTH | ERR_LEAF_RANGE)) why += " octree deeper than 14 levels;";
             if (err & ERR_CELL_RANGE) why += " voxel outside its leaf grid;";
             if (err & ERR_LIST_FULL) why += " occupied list full;";
-            if (err & ERR_POOL) why += " record pool full;";
             if (err & 0x80000000u) why += " device allocation or sort failure;";
             cwipc_log(CWIPC_LOG_LEVEL_ERROR, "cwipc_downsample", "voxel grid failed:" + why);
             return nullptr;
