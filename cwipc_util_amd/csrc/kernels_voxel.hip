@@ -131,6 +131,7 @@ enum {
 struct VoxParams {
     size_t n;
     size_t per_wave;        // points per wave range (multiple of WAVE_STEP)
+    uint32_t range_base_q, range_inc_q;   // != 0: the ranges the replay kernel gets boxes of have growing lengths (range_first_step)
     uint32_t nranges;       // number of wave ranges = waves in the K1 grid
     float inv_leaf;         // 1 / leaf in fp32, as pcl::VoxelGrid::setLeafSize
     float leaf;
@@ -163,6 +164,14 @@ struct VoxWork {
     uint32_t *dump_head;             // r4, fast accumulate kernel with FastParams::dump: per workgroup a DumpHead ...
     uint32_t *dump_ent;              //   ... and room for the entries of its table, DUMP_ENTRY_WORDS words each (voxel_k1_fast.inc)
 };
+
+// Ranges of growing length (r4, the fast accumulate kernel's workgroups: they then reach their flush one after the other instead of
+// all at once): range b has base_q + b * inc_q 1024ths of a step (256 points); this is the first step of range b.  Shared by the
+// accumulate kernel, the replay kernel (which reads a range again when its box does not settle the octree's growth) and the host.
+inline __host__ __device__ uint32_t range_first_step(uint32_t b, uint32_t base_q, uint32_t inc_q) {
+    const unsigned long long bb = b;
+    return (uint32_t)((bb * base_q + (unsigned long long)inc_q * (bb * (bb > 0 ? bb - 1 : 0) / 2)) >> 10);
+}
 
 inline __host__ __device__ uint64_t mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
@@ -1321,8 +1330,14 @@ __global__ void __launch_bounds__(1024) octree_replay_kernel(VoxParams P, const 
         }
 
         // replay that range in index order, a tile of 4096 points at a time
-        const size_t r_lo = (size_t)hit * P.per_wave;
-        const size_t r_hi = r_lo + P.per_wave < P.n ? r_lo + P.per_wave : P.n;
+        size_t r_lo = (size_t)hit * P.per_wave;
+        size_t r_hi = r_lo + P.per_wave < P.n ? r_lo + P.per_wave : P.n;
+        if (P.range_base_q != 0u) {
+            r_lo = (size_t)range_first_step((uint32_t)hit, P.range_base_q, P.range_inc_q) * WAVE_STEP;
+            r_hi = (size_t)range_first_step((uint32_t)hit + 1u, P.range_base_q, P.range_inc_q) * WAVE_STEP;
+            r_lo = r_lo < P.n ? r_lo : P.n;
+            r_hi = r_hi < P.n ? r_hi : P.n;
+        }
         for (size_t tile = r_lo; tile < r_hi; tile += 4096) {
             const size_t base = tile + (size_t)tid * 4;
             float qx[4], qy[4], qz[4];
@@ -2462,7 +2477,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             Wk.bboxes = ws.bboxes + (size_t)ws.bbox_cap * 6;   // the boxes of the moved points: nobody reads them
         }
         used_fast = fast;
-        uint32_t fast_blocks = 0, fast_per_wg = 0;
+        uint32_t fast_blocks = 0, fast_per_wg = 0, range_base_q = 0, range_inc_q = 0;
         if (fast) {
             FastParams F;
             memset(&F, 0, sizeof(F));
@@ -2478,7 +2493,31 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             const size_t wg_steps = std::min<size_t>(std::max<size_t>((steps_total + slots - 1) / slots, 1), MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP);
             fast_blocks = (uint32_t)((steps_total + wg_steps - 1) / wg_steps);
             fast_per_wg = (uint32_t)(wg_steps * WAVE_STEP);
+            // r4: the ranges' lengths grow linearly with the workgroup's number, from (1 - p %) to (1 + p %) of the mean, so that the
+            // workgroups reach their flush one after the other: the memory side takes ~10 us for all the flushes' atomics (112 k
+            // entries x seven), during which nothing streams when 248 workgroups arrive within two microseconds.  The longest range
+            // sets the kernel's end now (a workgroup's streaming time goes with its length: the vector port, not the memory, bounds it),
+            // so only part of those 10 us comes back: 53.9-54.4 -> 51.2-51.9 us alone at p = 20-25, 15 does nothing, 30-40 lose it again;
+            // a call in a stream is what it was (47-48 us: there the next kernel's workgroups fill the gaps anyway), call-then-count
+            // 66.0 -> 64.2 (profiles/r04_k1_stagger.txt).  CWIPC_K1_STAGGER=p overrides (0: equal ranges, rounds 1-3).  Only for
+            // ranges of 24 steps or more (clouds from 1.5 M points): a short range is mostly set-up and flush.
+            static const int stagger_knob = []() { const char *e = getenv("CWIPC_K1_STAGGER"); return e ? atoi(e) : 25; }();
+            if (stagger_knob > 0 && stagger_knob < 60 && fast_blocks >= 64 && !pair && steps_total >= (size_t)24 * fast_blocks) {
+                const double mean_q = (double)steps_total * 1024.0 / (double)fast_blocks, s_frac = stagger_knob / 100.0;
+                const size_t max_steps = MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP;
+                uint32_t inc = (uint32_t)ceil(2.0 * s_frac * mean_q / (double)(fast_blocks - 1));
+                uint32_t base = (uint32_t)ceil(mean_q * (1.0 - s_frac));
+                while (range_first_step(fast_blocks, base, inc) < steps_total) base++;
+                const size_t longest = (size_t)((base + (unsigned long long)(fast_blocks - 1) * inc + 2047) >> 10);
+                if (base >= 1024 && longest <= max_steps) {
+                    range_base_q = base; range_inc_q = inc;
+                    fast_per_wg = (uint32_t)(longest * WAVE_STEP);
+                }
+            }
             F.n = K.n; F.per_wg = fast_per_wg; F.inv_leaf = K.inv_leaf;
+            F.range_base_q = range_base_q; F.range_inc_q = range_inc_q;
+            static const bool stagger_rev = []() { const char *e = getenv("CWIPC_K1_STAGGER_REV"); return e && atoi(e) != 0; }();
+            F.range_reverse = range_base_q != 0u && stagger_rev ? 1u : 0u;
             F.ib0 = K.ib0; F.ib1 = K.ib1; F.ib2 = K.ib2;
             F.fb0 = K.fb0; F.fb1 = K.fb1; F.fb2 = K.fb2;
             F.leaf_mask = K.leaf_mask; F.list_cap = K.list_cap; F.want_list = K.want_list;
@@ -2548,6 +2587,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
         if (fast) {
             Pr.per_wave = fast_per_wg;
             Pr.nranges = fast_blocks;
+            Pr.range_base_q = range_base_q; Pr.range_inc_q = range_inc_q;
         } else if (partition) {   // the counting kernel's boxes: one per workgroup range of the cloud as it came
             Pr.per_wave = P.per_wave * K1_WAVES;
             Pr.nranges = nblocks;
