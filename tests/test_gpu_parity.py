@@ -1131,6 +1131,35 @@ def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
         assert same(a[key], b[key]), (knob, key)
 
 
+@pytest.mark.parametrize("env", [{"CWIPC_K1_STAGGER": "0"}, {"CWIPC_K1_STAGGER": "40"}, {"CWIPC_K1_STAGGER": "25", "CWIPC_K1_STAGGER_REV": "1"}])
+def test_staggered_ranges_change_no_result(gpu, synth, env, tmp_path):
+    """The fast accumulate kernel's workgroups take ranges of growing length (r4: 0.75 to 1.25 of the mean, so that their flushes do
+    not arrive together; clouds from 1.5 M points).  Equal ranges (rounds 1-3), a steeper slope and the reverse order give, bit for
+    bit, the same clouds: integer sums do not care where a range ends, and the replay kernel reads the ranges the accumulate kernel
+    took (range_first_step, kernels_voxel.hip)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pts, cs = synth(2_500_000, 0.3)
+    np.save(str(tmp_path / "pts.npy"), pts)
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import cwipc_util_amd as cw\n"
+        "pts = np.load(%r); out = {}\n"
+        "pc = cw.cwipc_from_numpy_array(pts, 1); pc._set_cellsize(%r)\n"
+        "for c in (0.01, -0.01, 0.003):\n"
+        "    for i in range(4): out['c%%s_%%d' %% (c, i)] = cw.cwipc_downsample(pc, c).get_numpy_array()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (root, str(tmp_path / "pts.npy"), cs)
+    ours, theirs = str(tmp_path / "default.npz"), str(tmp_path / "knob.npz")
+    subprocess.run([sys.executable, "-c", code, ours], check=True, timeout=600, env={k: v for k, v in os.environ.items() if not k.startswith("CWIPC_K1_STAGGER")})
+    subprocess.run([sys.executable, "-c", code, theirs], check=True, timeout=600, env=dict(os.environ, **env))
+    a, b = np.load(ours), np.load(theirs)
+    assert sorted(a.keys()) == sorted(b.keys())
+    for key in a.keys():
+        assert len(a[key]) > 1000 and same(a[key], b[key]), (env, key)
+
+
 def test_sor_sparse_and_dense_grid_layouts_agree(gpu, oracle, synth):
     """The k-NN grid has two layouts: dense (small clouds) and segments of 16 cells that exist only where points are (big
     clouds, kernels_sor.hip).  d_i is a property of the cloud, not of the search structure: both layouts, forced through
