@@ -2502,7 +2502,7 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             // 66.0 -> 64.2 (profiles/r04_k1_stagger.txt).  CWIPC_K1_STAGGER=p overrides (0: equal ranges, rounds 1-3).  Only for
             // ranges of 24 steps or more (clouds from 1.5 M points): a short range is mostly set-up and flush.
             static const int stagger_knob = []() { const char *e = getenv("CWIPC_K1_STAGGER"); return e ? atoi(e) : 25; }();
-            if (stagger_knob > 0 && stagger_knob < 60 && fast_blocks >= 64 && !pair && steps_total >= (size_t)24 * fast_blocks) {
+            if (stagger_knob > 0 && stagger_knob < 60 && fast_blocks >= 64 && !pair && steps_total >= (size_t)24 * fast_blocks && n < ((size_t)1 << 31)) {
                 const double mean_q = (double)steps_total * 1024.0 / (double)fast_blocks, s_frac = stagger_knob / 100.0;
                 const size_t max_steps = MAX_POINTS_PER_WAVE * K1_WAVES / WAVE_STEP;
                 uint32_t inc = (uint32_t)ceil(2.0 * s_frac * mean_q / (double)(fast_blocks - 1));
