@@ -1912,7 +1912,8 @@ struct Workspace {
     size_t dump_blocks = 0, dump_entries = 0;             //   ... for this many workgroups of this many table entries
     float *part = nullptr;             // partition pass: the cloud moved into spatial buckets, four planes of part_stride elements
     size_t part_stride = 0;
-    uint32_t *part_hist = nullptr;     //   ... and its PART_BUCKETS bucket counts / cursors
+    uint32_t *part_hist = nullptr;     //   ... and its table: a row of PART_BUCKETS counts per range, the rows' sums by segments, the buckets' starts
+    size_t part_rows = 0;              //   (room for this many rows)
     uint32_t *ctrl = nullptr;
     uint32_t *bitmaps = nullptr;
     uint32_t *seg_count = nullptr;
@@ -1924,7 +1925,7 @@ struct Workspace {
     void drop_partition_buffers() {
         if (part) { (void)hipFree(part); g_workspace_bytes -= 16 * part_stride; }
         if (part_hist) (void)hipFree(part_hist);
-        part = nullptr; part_hist = nullptr; part_stride = 0;
+        part = nullptr; part_hist = nullptr; part_stride = 0; part_rows = 0;
     }
     void drop_dump_buffers() {
         if (dump_head) (void)hipFree(dump_head);
@@ -2376,16 +2377,19 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     static const bool partition_off = []() { const char *e = getenv("CWIPC_VOXEL_PARTITION"); return e && atoi(e) == 0; }();   // test knob
     const bool partition = ws.incoherent && !partition_off && n >= 65536;
     const size_t part_stride = (n + 1023) & ~(size_t)1023;
+    const size_t part_nseg = (nblocks + PART_SEG_ROWS - 1) / PART_SEG_ROWS;
     if (partition) {
-        if (ws.part_stride < part_stride) {
+        if (ws.part_stride < part_stride || ws.part_rows < nblocks) {
             ws.drop_partition_buffers();
-            if (hipMalloc((void **)&ws.part, 16 * part_stride) != hipSuccess || hipMalloc((void **)&ws.part_hist, (size_t)PART_BUCKETS * PART_PAD * sizeof(uint32_t)) != hipSuccess) {
+            if (hipMalloc((void **)&ws.part, 16 * part_stride) != hipSuccess ||
+                hipMalloc((void **)&ws.part_hist, ((size_t)nblocks + part_nseg + 1) * PART_BUCKETS * sizeof(uint32_t)) != hipSuccess) {
                 (void)hipGetLastError();
                 ws.drop_partition_buffers();
                 hip_failed(hipErrorOutOfMemory, "voxel partition buffers", __FILE__, __LINE__);
                 return nullptr;
             }
             ws.part_stride = part_stride;
+            ws.part_rows = nblocks;
             g_workspace_bytes += 16 * part_stride;
         }
     } else if (ws.part) {
@@ -2464,15 +2468,16 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
             float *px = ws.part, *py = px + ws.part_stride, *pz = py + ws.part_stride;
             uint32_t *pw = (uint32_t *)(pz + ws.part_stride);
             const uint32_t padded = (uint32_t)((n + WAVE_STEP - 1) / WAVE_STEP * WAVE_STEP);
-            if (hipMemsetAsync(ws.part_hist, 0, (size_t)PART_BUCKETS * PART_PAD * sizeof(uint32_t), c.stream) != hipSuccess) {
-                hip_failed(hipGetLastError(), "voxel partition setup", __FILE__, __LINE__);
-                return nullptr;
-            }
-            CW_LAUNCH("partition_count", partition_count_kernel, dim3(nblocks), dim3(K1_THREADS), 0, c.stream, (uint32_t)n, (uint32_t)(P.per_wave * K1_WAVES), P.inv_leaf,
-                      src.x(), src.y(), src.z(), ws.bboxes, ws.part_hist, ws.ctrl);
-            CW_LAUNCH("partition_scan", partition_scan_kernel, dim3(1), dim3(K1_THREADS), 0, c.stream, ws.part_hist);
-            CW_LAUNCH("partition_scatter", partition_scatter_kernel, dim3((unsigned)((n + PART_CHUNK - 1) / PART_CHUNK)), dim3(K1_THREADS), sizeof(PartLds), c.stream,
-                      (uint32_t)n, padded, P.inv_leaf, src.x(), src.y(), src.z(), src.rgbt(), px, py, pz, pw, ws.part_hist);
+            // the table: rows [part_rows][buckets], then the segments' sums [nseg][buckets], then the buckets' starts (every word is
+            // written by the kernels that follow: nothing to clear)
+            uint32_t *rows = ws.part_hist, *seg = rows + ws.part_rows * PART_BUCKETS, *start = seg + part_nseg * PART_BUCKETS;
+            const uint32_t per_wg = (uint32_t)(P.per_wave * K1_WAVES);
+            CW_LAUNCH("partition_count", partition_count_kernel, dim3(nblocks), dim3(K1_THREADS), 0, c.stream, (uint32_t)n, per_wg, P.inv_leaf,
+                      src.x(), src.y(), src.z(), ws.bboxes, rows, ws.ctrl);
+            CW_LAUNCH("partition_scan", partition_segsum_kernel, dim3((unsigned)part_nseg, PART_BUCKETS / 256), dim3(256), 0, c.stream, rows, nblocks, seg);
+            CW_LAUNCH("partition_scan", partition_starts_kernel, dim3(1), dim3(K1_THREADS), 0, c.stream, seg, (uint32_t)part_nseg, start);
+            CW_LAUNCH("partition_scatter", partition_scatter_kernel, dim3(nblocks), dim3(K1_THREADS), sizeof(PartLds), c.stream,
+                      (uint32_t)n, per_wg, padded, P.inv_leaf, src.x(), src.y(), src.z(), src.rgbt(), px, py, pz, pw, rows, seg, start);
             kx = px; ky = py; kz = pz; kw = pw;
             Wk.bboxes = ws.bboxes + (size_t)ws.bbox_cap * 6;   // the boxes of the moved points: nobody reads them
         }
