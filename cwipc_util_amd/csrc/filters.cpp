@@ -337,6 +337,39 @@ extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double wei
     auto dst = soa_with_new_rgbt(src);   // the coordinates do not change: the result holds the very same planes
     if (!dst) return nullptr;
     const int ndoubles = 1025 + 256;
+    // (r4) A stream of frames colours every tile with the same weight and map: the table of a (device, weight, map) stays on the
+    // device -- up to sixteen of them for the life of the process -- and a call that finds its table there is one kernel launch that
+    // nobody waits for (the result carries an event, the input remembers its reader).  Round 3's call built the table, copied it
+    // and waited for the kernel: 35 us per camera tile in config 5's chain, most of it the wait.
+    struct CachedTable { int device; double weight; double lut[768]; uint8_t valid[256]; double *dev; };
+    static std::mutex cache_mutex;
+    static std::vector<CachedTable *> cache;
+    double *dev_table = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(cache_mutex);
+        for (CachedTable *t : cache)
+            if (t->device == src->device && memcmp(&t->weight, &weight, sizeof(double)) == 0 && memcmp(t->lut, lut, sizeof(t->lut)) == 0 &&
+                memcmp(t->valid, valid, sizeof(t->valid)) == 0) { dev_table = t->dev; break; }
+    }
+    if (dev_table && !profiling_enabled()) {
+        // (on the thread's second stream: cwipc_downsample takes "the thread's first stream is busy" for calls that come faster than
+        // its workspace turns around and answers with another workspace, 0.3 GB of leaf grids -- a kernel of this filter in flight
+        // there made every thread of config 5's chain hold three, test_config5_eight_threads_workspace_footprint)
+        hipStream_t s = c.stream_alt ? c.stream_alt : c.stream;
+        if (s != c.stream) src->wait_on(s);   // (device_input has ordered the first stream behind the input's producer, not this one)
+        k::map_colorize(*src, *dst, dev_table, s);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            hip_failed(e, "cwipc_hip_colorize", __FILE__, __LINE__);
+            (void)c.sync();
+            return nullptr;
+        }
+        dst->mark_pending(s);
+        src->note_reader(s);
+        inherit_first(*dst, *src);
+        dst->set_tiles_from(*src);   // (colours change, tiles do not)
+        return wrap(dst, pc->timestamp(), pc->cellsize());
+    }
+    const bool cached = dev_table != nullptr;
     double *host_table = (double *)c.staging(ndoubles * sizeof(double));
     if (!host_table) return nullptr;
     // the same IEEE double operations Python performs, in the same order
@@ -345,12 +378,28 @@ extern "C" cwipc_pointcloud *cwipc_hip_colorize(cwipc_pointcloud *pc, double wei
     for (int v = 0; v < 256; v++) host_table[768 + v] = v / 255.0;
     host_table[1024] = 1 - weight;
     for (int t = 0; t < 256; t++) host_table[1025 + t] = valid[t] ? 1.0 : 0.0;
-    double *dev_table = (double *)pool_alloc(ndoubles * sizeof(double));
-    if (!dev_table) return nullptr;
-    bool ok = hipMemcpyAsync(dev_table, host_table, ndoubles * sizeof(double), hipMemcpyHostToDevice, c.stream) == hipSuccess;
+    bool ok = true;
+    if (!cached) {
+        dev_table = (double *)pool_alloc(ndoubles * sizeof(double));
+        if (!dev_table) return nullptr;
+        ok = hipMemcpyAsync(dev_table, host_table, ndoubles * sizeof(double), hipMemcpyHostToDevice, c.stream) == hipSuccess;
+    }
     if (ok) k::map_colorize(*src, *dst, dev_table, c.stream);
     ok = c.sync() && ok;
-    pool_free(dev_table);
+    if (!cached) {
+        bool kept = false;
+        if (ok) {
+            std::lock_guard<std::mutex> lock(cache_mutex);
+            if (cache.size() < 16) {
+                auto *t = new CachedTable();
+                t->device = src->device; t->weight = weight; t->dev = dev_table;
+                memcpy(t->lut, lut, sizeof(t->lut)); memcpy(t->valid, valid, sizeof(t->valid));
+                cache.push_back(t);   // (the block stays out of the pool from here on)
+                kept = true;
+            }
+        }
+        if (!kept) pool_free(dev_table);
+    }
     if (!ok) return nullptr;
     inherit_first(*dst, *src);
     dst->set_tiles_from(*src);   // (colours change, tiles do not)
@@ -436,6 +485,7 @@ extern "C" cwipc_pointcloud *cwipc_downsample(cwipc_pointcloud *pc, float cellsi
         who = "cwipc_downsample_voxelgrid";
     }
     if (pc == nullptr) return nullptr;
+    if (cwipc_hip_device_count() > current_device()) voxel_sample_streams();   // (before the input puts a wait into this thread's stream)
     std::unique_ptr<cwipc_hip_pointcloud> keep;
     auto src = device_input(who, pc, keep);
     if (!src) return nullptr;

@@ -382,6 +382,7 @@ void join_copy(const JoinPart &part, const DeviceSoA &dst, hipStream_t s);
 // nullptr (error already logged).  leaf_split = positive-cellsize path.
 // With `deferred` (octree path only) the call may come back before its kernels are done: it then returns nullptr and
 // leaves the pending result in *deferred.
+void voxel_sample_streams();   // which of the calling thread's workspace streams are at work: call before the input is resolved (kernels_voxel.hip)
 std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &src, float cellsize, bool leaf_split, int *error_code,
                                             std::shared_ptr<DeferredResult> *deferred = nullptr);
 

@@ -230,6 +230,173 @@ __global__ void __launch_bounds__(BLK) count_nonzero_kernel(const uint32_t *__re
     }
 }
 
+// starts = exclusive prefix sums of counts over the cells of the grid the device decided on (gm->g): ONE workgroup, for the
+// small clouds of the dense layout (a camera tile of a frame: a few ten thousand cells).  rocprim's scan runs over the whole
+// allocation (the host does not know the grid: 8 cells per point whatever the kernels made of them) in two launches, 9 + 3 us for
+// such a tile; this one reads the cell count where the grid is and takes a pass to add and a pass to write.
+constexpr int SCAN1_THREADS = 1024;
+__global__ void __launch_bounds__(SCAN1_THREADS) small_scan_kernel(const GridMeta *__restrict__ gm, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ counts2,
+                                                                  uint32_t *__restrict__ starts, size_t cap) {
+    __shared__ uint32_t wsum[SCAN1_THREADS / 64];
+    if (counts2 && gm[1].refine) { gm += 1; counts = counts2; }   // the small clouds' flow: the coarser grid's slot and counts
+    size_t ncells = grid_cells(gm->g);
+    if (ncells > cap) ncells = cap;
+    // A contiguous share per thread, in whole 16-byte groups (the arrays are pool blocks, cap is a multiple of four, and what lies
+    // between the grid's last cell and the end of its group is zeroes): one pass to add the share up -- loads that do not depend on
+    // each other, all in flight together --, the scan over the threads, a second pass over the same words (they are in L2 now) to
+    // write the prefixes.  Two memory round trips and one barrier whatever the grid's size.  (First version: tiles of 16 k cells
+    // through registers, a round trip and a barrier per tile: 13 us for 35 k cells against 6 for an empty kernel of this shape; with
+    // the tile's loads under a condition the compiler made sixteen one-word loads behind branches of each: 25 us.)
+    const size_t nvec = (ncells + 3) / 4, per = (nvec + SCAN1_THREADS - 1) / SCAN1_THREADS;
+    const size_t v0 = (size_t)threadIdx.x * per < nvec ? (size_t)threadIdx.x * per : nvec, v1 = v0 + per < nvec ? v0 + per : nvec;
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(counts);
+    uint4 *s4 = reinterpret_cast<uint4 *>(starts);
+    uint32_t mine = 0;
+#pragma unroll 8
+    for (size_t v = v0; v < v1; v++) {
+        const uint4 q = c4[v];
+        mine += q.x + q.y + q.z + q.w;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+#pragma unroll
+    for (int w = 0; w < SCAN1_THREADS / 64; w++) {
+        const uint32_t t = wsum[w];
+        if (w < wave) before += t;
+    }
+#pragma unroll 8
+    for (size_t v = v0; v < v1; v++) {
+        const uint4 q = c4[v];
+        s4[v] = make_uint4(before, before + q.x, before + q.x + q.y, before + q.x + q.y + q.z);
+        before += q.x + q.y + q.z + q.w;
+    }
+}
+
+// ---- small clouds (r4): the dense layout in ten launches instead of twelve ----
+// A camera tile of a frame (a few ten thousand points) is filtered in ~0.1 ms, most of it the chain of small kernels in front of
+// the search.  Here the box kernel also clears the per-cell arrays (their size is the host's: 8 cells per point), EVERY workgroup of
+// the first count derives the grid from the partial boxes itself (a few KB from L2 and one lane's arithmetic: the same grid in every
+// workgroup) and the first one writes it down; every workgroup of the second count takes the coarsening decision from the same
+// two words and, if it stands, derives the coarser grid itself and counts into an array of its own (cleared with the others), the
+// first one writing the grid into the block's second slot.  What follows reads slot 1 if its `refine` says so, slot 0 otherwise.
+__device__ __forceinline__ void finest_grid(const float lo[3], const float hi[3], size_t cap_cells, GridMeta &m) {   // grid_setup_zero_kernel's arithmetic
+    Grid g;
+    double ext[3], maxext = 0;
+    for (int a = 0; a < 3; a++) {
+        g.mn[a] = lo[a] == FLT_MAX ? 0.f : lo[a];
+        ext[a] = (double)hi[a] - (double)lo[a];
+        if (!(ext[a] >= 0)) ext[a] = 0;   // no finite point
+        if (ext[a] > maxext) maxext = ext[a];
+    }
+    if (!(maxext > 0)) maxext = 1.0;
+    double h = maxext / 1024.0;
+    grid_dims(g, ext, h);
+    while (grid_cells(g) > cap_cells) { h *= 1.25; grid_dims(g, ext, h); }
+    m.g = g;
+    for (int a = 0; a < 3; a++) m.ext[a] = ext[a];
+    m.maxext = maxext;
+}
+
+__global__ void __launch_bounds__(BLK) small_bbox_zero_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
+                                                             float *__restrict__ partial /* [gridDim.x][6] */, uint32_t *__restrict__ words, size_t nwords,
+                                                             GridMeta *__restrict__ m) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint4 *w4 = reinterpret_cast<uint4 *>(words);
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < nwords / 4; i += (size_t)gridDim.x * BLK) w4[i] = zero;   // (nwords: a multiple of four)
+    if (blockIdx.x == 0 && threadIdx.x < 2) { m[threadIdx.x].occ = 0; m[threadIdx.x].refine = 0; }
+    __shared__ float red[6][BLK / 64];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        float v[3] = {x[i], y[i], z[i]};
+        if (!(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]))) continue;
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], v[a]); hi[a] = fmaxf(hi[a], v[a]); }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[threadIdx.x][0];
+        for (int w = 1; w < BLK / 64; w++) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+        partial[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// PHASE 0: grid from the partial boxes, count + census into counts, slot 0.  PHASE 1: the coarser grid if the census asks for one,
+// count into counts2, slot 1.
+template <int PHASE>
+__global__ void __launch_bounds__(BLK) small_count_kernel(const float *__restrict__ partial, unsigned nb, size_t cap_cells, double target, GridMeta *__restrict__ m,
+                                                         const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
+                                                         uint32_t *__restrict__ counts, uint32_t *__restrict__ cell_id) {
+    __shared__ GridMeta sm;
+    __shared__ uint32_t wsum[BLK / 64];
+    if (PHASE == 0) {
+        if (threadIdx.x < 64) {
+            float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (unsigned b = threadIdx.x; b < nb; b += 64)
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], partial[b * 6 + a]); hi[a] = fmaxf(hi[a], partial[b * 6 + 3 + a]); }
+            for (int a = 0; a < 3; a++)
+                for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64)); hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64)); }
+            if (threadIdx.x == 0) {
+                finest_grid(lo, hi, cap_cells, sm);
+                if (blockIdx.x == 0) { m[0].g = sm.g; for (int a = 0; a < 3; a++) m[0].ext[a] = sm.ext[a]; m[0].maxext = sm.maxext; }   // (occ: the census's adds, cleared by the box kernel)
+            }
+        }
+    } else {
+        const uint32_t occ = m[0].occ;
+        const double ppc = (double)n / (double)(occ ? occ : 1u);
+        if (!(ppc < target)) return;   // the census's grid stands, and its counts (the whole workgroup leaves: the same words for every thread)
+        if (threadIdx.x == 0) {
+            double h = m[0].g.h * sqrt(target / ppc);
+            if (h > m[0].maxext) h = m[0].maxext;
+            Grid g = m[0].g;
+            double ext[3] = {m[0].ext[0], m[0].ext[1], m[0].ext[2]};
+            grid_dims(g, ext, h);
+            sm.g = g;
+            if (blockIdx.x == 0) { m[1].g = g; m[1].refine = 1; }
+        }
+    }
+    __syncthreads();
+    const Grid g = sm.g;
+    uint32_t fresh = 0;
+    for (size_t base = (size_t)blockIdx.x * BLK; base < n; base += (size_t)gridDim.x * BLK) {
+        const size_t i = base + threadIdx.x;
+        const bool active = i < n;
+        uint32_t c = 0xffffffffu;
+        if (active) {
+            c = cell_of(g, x[i], y[i], z[i]);
+            cell_id[i] = c;
+        }
+        const WaveRun r = wave_run(c, active);
+        if (PHASE == 0) {
+            if (r.leads && atomicAdd(&counts[c], (uint32_t)r.length) == 0u) fresh++;
+        } else if (r.leads) {
+            atomicAdd(&counts[c], (uint32_t)r.length);
+        }
+    }
+    if (PHASE != 0) return;
+    for (int off = 32; off > 0; off >>= 1) fresh += __shfl_down(fresh, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = fresh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < BLK / 64; w++) t += wsum[w];
+        if (t) atomicAdd(&m[0].occ, t);
+    }
+}
+
 // sorted[pos] = (x, y, z, original index)
 __global__ void __launch_bounds__(BLK) cell_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, size_t n,
                                                           const uint32_t *__restrict__ cell_id, const uint32_t *__restrict__ cell_start,
@@ -457,9 +624,10 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
 // SPARSE: cell_start is indexed by the cells that exist (one entry more than there are cells: the end), cell_count is the
 // segment table (seg_pack_kernel).
 template <int KCAP, bool SPARSE>
-__global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
+__global__ void __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(KCAP <= 17 ? 5 : 4))) knn_mean_dist_reg_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
                                                               const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_count, int k,
-                                                              float *__restrict__ dist_out) {
+                                                              float *__restrict__ dist_out, const uint32_t *__restrict__ cell_count2 = nullptr) {
+    if (cell_count2 && gm[1].refine) { gm += 1; cell_count = cell_count2; }   // the small clouds' flow: the coarser grid's slot and counts
     const Grid g = gm ? gm->g : gv;
     const int want = k + 1, pad = KCAP - want;
     size_t qi = (size_t)blockIdx.x * QB + threadIdx.x;
@@ -550,24 +718,41 @@ __global__ void __launch_bounds__(QB) knn_mean_dist_reg_kernel(Grid gv, const Gr
     const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
     for (int ring = 1; ring <= maxring; ring++) {
         if (ring > 1) {
+            // (r4) Shells beyond the first: the queries at a cloud's edge, a few lanes of every wave, and the whole wave waits for them.
+            // A row (or an end cell of an inner row) is looked up only if it can still hold one of the k + 1 nearest: the squared distance
+            // from the query to the row's cells, from the cells' faces in f64 (the cell of a point is floor((v - mn) / h) in f64 too),
+            // against the worst distance kept, with the margin the ring's own exit test below takes.  Without the test a lane in ring 2
+            // walked through 34 dependent pairs of loads (row index, candidates), most of them for cells on the far side.
             const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dim[0] - 1);
+            // (the margin goes in once, in f64, before the value is rounded to fp32: what is added up below in fp32 stays under the true
+            // distance by more than the three roundings of the candidates' own fp32 distances)
+            auto gap2 = [&](float v, int a, int cell, int o) -> float {   // squared distance from v to the cells `o` cells away from `cell` on axis a
+                if (o == 0) return 0.f;
+                const double face = (double)g.mn[a] + (double)(o < 0 ? cell + o + 1 : cell + o) * g.h;
+                const double d = o < 0 ? (double)v - face : face - (double)v;
+                return d > 0.0 ? (float)(d * d * (1.0 - 1e-6)) : 0.f;
+            };
+            const float gx_lo = gap2(q.x, 0, cx, -ring), gx_hi = gap2(q.x, 0, cx, ring);
             for (int dz = -ring; dz <= ring; dz++) {
                 const int z = cz + dz;
                 if (z < 0 || z >= g.dim[2]) continue;
+                const float gz = gap2(q.z, 2, cz, dz);
                 for (int dy = -ring; dy <= ring; dy++) {
                     const int y = cy + dy;
                     if (y < 0 || y >= g.dim[1]) continue;
+                    const float gyz = gz + gap2(q.y, 1, cy, dy);
+                    if (gyz >= best[KCAP - 1]) continue;
                     const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
                     uint32_t first, last;
                     if (face) {   // the whole row belongs to the shell
                         row_range(x0, x1, y, z, first, last);
                         scan(first, last);
                     } else {      // only its two end cells do
-                        if (cx - ring >= 0) {
+                        if (cx - ring >= 0 && gyz + gx_lo < best[KCAP - 1]) {
                             row_range(cx - ring, cx - ring, y, z, first, last);
                             scan(first, last);
                         }
-                        if (cx + ring < g.dim[0]) {
+                        if (cx + ring < g.dim[0] && gyz + gx_hi < best[KCAP - 1]) {
                             row_range(cx + ring, cx + ring, y, z, first, last);
                             scan(first, last);
                         }
@@ -698,6 +883,51 @@ bool sor_dense_on_device(const DeviceSoA &src, int k, float *dev_dist, float *pa
     return true;
 }
 
+// The same for small clouds (cap <= 2^19 cells: up to 64 k points; k + 1 <= 33): ten launches with the compaction behind it, see small_bbox_zero_kernel.
+bool sor_small_on_device(const DeviceSoA &src, int k, float *dev_dist, size_t cap, ThreadCtx &c) {
+    const size_t n = src.npoints;
+    double target = (double)(k + 1) / 2.0;
+    if (const char *t = getenv("CWIPC_SOR_CELL_TARGET")) target = (double)(k + 1) * atof(t);   // tuning knob: points per occupied cell / (k + 1)
+    const unsigned nb = std::min(256u, grid_for(n));
+    float *partial = (float *)pool_alloc((size_t)nb * 6 * sizeof(float));
+    GridMeta *meta = (GridMeta *)pool_alloc(2 * sizeof(GridMeta));
+    uint32_t *words = (uint32_t *)pool_alloc(3 * cap * sizeof(uint32_t));   // counts | counts of the coarser grid | the scatter's cursor
+    uint32_t *starts = (uint32_t *)pool_alloc(cap * sizeof(uint32_t));
+    uint32_t *cell_id = (uint32_t *)pool_alloc(n * sizeof(uint32_t));
+    float4 *sorted = (float4 *)pool_alloc(n * sizeof(float4));
+    auto give_back = [&](bool later) {
+        void *all[] = {partial, meta, words, starts, cell_id, sorted};
+        for (void *b : all) { if (later) c.free_later(b); else pool_free(b); }
+    };
+    if (!partial || !meta || !words || !starts || !cell_id || !sorted) {
+        (void)c.sync();
+        give_back(false);
+        return hip_failed(hipErrorOutOfMemory, "sor workspace", __FILE__, __LINE__);
+    }
+    uint32_t *counts = words, *counts2 = words + cap, *cursor = words + 2 * cap;
+    const Grid unused{};
+    const unsigned pgrid = grid_for(n);
+    CW_LAUNCH("sor_bbox", small_bbox_zero_kernel, dim3(nb), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, partial, words, 3 * cap, meta);
+    CW_LAUNCH("sor_cell_count", small_count_kernel<0>, dim3(pgrid), dim3(BLK), 0, c.stream, partial, nb, cap, target, meta, src.x(), src.y(), src.z(), n, counts, cell_id);
+    CW_LAUNCH("sor_cell_count", small_count_kernel<1>, dim3(pgrid), dim3(BLK), 0, c.stream, partial, nb, cap, target, meta, src.x(), src.y(), src.z(), n, counts2, cell_id);
+    CW_LAUNCH("sor_exclusive_scan", small_scan_kernel, dim3(1), dim3(SCAN1_THREADS), 0, c.stream, meta, counts, counts2, starts, cap);
+    CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(pgrid), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts, cursor, sorted);
+    const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
+    if (k + 1 <= 17) {
+        CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist, counts2);
+    } else {
+        CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist, counts2);
+    }
+    if (hipGetLastError() != hipSuccess) {
+        hip_failed(hipGetLastError(), "sor k-NN", __FILE__, __LINE__);
+        (void)c.sync();
+        give_back(false);
+        return false;
+    }
+    give_back(true);
+    return true;
+}
+
 }  // namespace
 
 bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
@@ -711,14 +941,21 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
     }
     // (any k, as the reference: lists in registers up to k = 32, in LDS up to k = 319, in device memory beyond: launch_knn_list)
 
+    static const int sparse_knob = []() { const char *e = getenv("CWIPC_SOR_SPARSE"); return e ? atoi(e) : -1; }();   // test knob: 1 always, 0 never
+    const bool sparse = (sparse_knob == 1 || (sparse_knob != 0 && n >= ((size_t)1 << 20))) && k + 1 <= 33;
+    static const bool host_grid = []() { const char *e = getenv("CWIPC_SOR_HOST_GRID"); return e && atoi(e) != 0; }();   // test knob: the dense layout decided by the host
+    if (!sparse && !host_grid && k + 1 <= 33) {
+        // (r4) small clouds: two launches fewer and a one-workgroup scan over the cells the grid really has
+        static const size_t cells_per_point = []() { const char *e = getenv("CWIPC_SOR_CELLS_PER_POINT"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)8; }();   // tuning knob
+        static const size_t small_cells = []() { const char *e = getenv("CWIPC_SOR_SMALL_CELLS"); return e ? (size_t)atol(e) : (size_t)1 << 19; }();   // 0: never (test knob)
+        const size_t cap = std::min<size_t>(MAX_CELLS, std::max<size_t>((size_t)1 << 16, cells_per_point * n));
+        if (cap <= small_cells) return sor_small_on_device(src, k, dev_dist, cap, c);
+    }
     // 1. bounding box
     const unsigned nb = grid_for(n);
     float *partial = (float *)pool_alloc((size_t)nb * 6 * sizeof(float));
     if (!partial) return false;
     CW_LAUNCH("sor_bbox", bbox_kernel, dim3(nb), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, partial);
-    static const int sparse_knob = []() { const char *e = getenv("CWIPC_SOR_SPARSE"); return e ? atoi(e) : -1; }();   // test knob: 1 always, 0 never
-    const bool sparse = (sparse_knob == 1 || (sparse_knob != 0 && n >= ((size_t)1 << 20))) && k + 1 <= 33;
-    static const bool host_grid = []() { const char *e = getenv("CWIPC_SOR_HOST_GRID"); return e && atoi(e) != 0; }();   // test knob: the dense layout decided by the host
     if (!sparse && !host_grid) return sor_dense_on_device(src, k, dev_dist, partial, nb, c);
     float *hpart = (float *)c.staging((size_t)nb * 6 * sizeof(float));
     bool ok = hpart && hipMemcpyAsync(hpart, partial, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
@@ -790,9 +1027,11 @@ bool sor_mean_distances(const DeviceSoA &src, int k, float *dev_dist) {
         };
         if (!census()) return fail();
         {
-            // coarsen so that an occupied cell holds about (k + 1) / 2 points (surface-like data: points per cell grow with h^2)
+            // coarsen so that an occupied cell holds about 0.3 (k + 1) points (surface-like data: points per cell grow with h^2).
+            // (r4: 0.5 (k + 1) until the shells beyond the first got their bound per row; with it finer cells pay: 2 M points 0.71 -> 0.66 ms,
+            // profiles/r04_sor_small_flow.txt.  10 M points are at the segment budget's cell size either way.)
             const double ppc = (double)n / (double)(occ_cells ? occ_cells : 1);
-            double target = (double)(k + 1) / 2.0;
+            double target = 0.3 * (double)(k + 1);
             if (const char *t = getenv("CWIPC_SOR_CELL_TARGET")) target = (double)(k + 1) * atof(t);
             if (ppc < target) {
                 double h = hs * sqrt(target / ppc);

@@ -2011,6 +2011,8 @@ struct WorkspaceLease {
 };
 thread_local WorkspaceLease t_ws;
 thread_local int t_ws_next = 0;
+thread_local uint32_t t_busy_sample = 0;    // bit i: the stream of this thread's workspace i had work in flight when cwipc_downsample was entered
+thread_local bool t_busy_sampled = false;  // ... valid for the call that follows (voxel_sample_streams)
 thread_local int t_ws_idle = 0;   // calls in a row that found both of the thread's streams idle while it holds a second workspace
 
 // For the duration of a call: the thread's current stream is the one of the workspace in use.
@@ -2193,6 +2195,24 @@ std::shared_ptr<DeviceSoA> PendingVoxel::settle() {
 
 }  // namespace
 
+// "Is the workspace whose turn it is still at work?" is asked of its stream -- and has to be asked BEFORE the call orders that stream
+// behind the producer of its input: a cloud that came out of another filter with its last kernel still running (r4: colorize, as
+// a join's result since round 2) puts a wait into the thread's first stream, which then reads as busy although the workspace has
+// been idle since the frame before, and every thread of a per-tile chain took a second and a third workspace (0.3 GB each) for
+// calls that could not overlap anyway.  cwipc_downsample samples the streams on entry; the call that follows uses the sample.
+void voxel_sample_streams() {
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return;
+    uint32_t bits = 0;
+    for (int i = 0; i < MAX_WS && t_ws.ws[i]; i++) {
+        hipStream_t s = i == 0 ? c.stream : i == 1 ? c.stream_alt : c.extra_stream(i - 2);
+        if (s && hipStreamQuery(s) == hipErrorNotReady) bits |= 1u << i;
+        (void)hipGetLastError();   // (hipErrorNotReady is an answer, not a failure)
+    }
+    t_busy_sample = bits;
+    t_busy_sampled = true;
+}
+
 std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &src_ptr, float cellsize, bool leaf_split, int *error_code,
                                             std::shared_ptr<DeferredResult> *deferred) {
     const DeviceSoA &src = *src_ptr;
@@ -2210,7 +2230,10 @@ std::shared_ptr<DeviceSoA> voxel_downsample(const std::shared_ptr<DeviceSoA> &sr
     int have = 0;
     while (have < MAX_WS && t_ws.ws[have]) have++;
     const auto stream_of = [&](int i) -> hipStream_t { return i == 0 ? c.stream : i == 1 ? c.stream_alt : c.extra_stream(i - 2); };
+    const bool sampled = t_busy_sampled;
+    t_busy_sampled = false;
     const auto busy = [&](int i) {
+        if (sampled) return ((t_busy_sample >> i) & 1u) != 0u;   // as the thread's streams were when the call came in (voxel_sample_streams)
         hipStream_t s = stream_of(i);
         const bool b = s && hipStreamQuery(s) == hipErrorNotReady;
         (void)hipGetLastError();   // (hipErrorNotReady is an answer, not a failure)
