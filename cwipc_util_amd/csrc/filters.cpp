@@ -523,7 +523,7 @@ std::shared_ptr<DeviceSoA> sor_once(const DeviceSoA &src, int k, float stddev_mu
     if (!dist) return nullptr;
     double *thr_dev = reinterpret_cast<double *>(reinterpret_cast<char *>(dist) + ((src.npoints * sizeof(float) + 127) & ~(size_t)127));
     std::shared_ptr<DeviceSoA> out;
-    if (sor_mean_distances(src, k, dist) && sor_threshold_device(dist, src.npoints, stddev_mul, thr_dev)) out = sor_select(src, dist, 0.0, thr_dev);
+    if (sor_mean_distances(src, k, dist)) out = sor_threshold_and_select(src, dist, stddev_mul, thr_dev);
     // every failure exit: kernels that read or write `dist` may still be in flight, and the block goes back to a pool
     // other threads allocate from
     if (!out) (void)tctx().sync();

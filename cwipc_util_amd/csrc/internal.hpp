@@ -335,9 +335,16 @@ struct Predicate {
     const float *dist;
     double thr;
     const double *thr_dev;   // mode 3: device address of the threshold when a kernel computed it (thr is ignored then)
+    // mode 3, small clouds (r4): the threshold is still 1024 pairs of partial sums (sor_stats_partial_device): the count kernel's workgroups run the
+    // statistics' tree themselves -- each the same tree -- and the first one writes the threshold to thr_out (= thr_dev) for the scatter kernel
+    const double *stat_partial;
+    size_t stat_n;
+    float stat_mul;
+    double *thr_out;
 };
 // Pass 1: per-block keep counts into block_counts[nblocks]; returns nblocks through the argument.
 size_t compact_blocks(size_t n);
+size_t compact_small_cloud_limit();   // clouds up to here go through compact_count_scan
 void compact_count(const DeviceSoA &src, const Predicate &p, uint32_t *block_counts, hipStream_t s);
 // count and scan in one launch (the last workgroup to finish scans the block counts): for clouds of up to a million points,
 // where a launch costs the host more than the kernel costs the device; `ticket`: a zeroed device word, left zeroed
@@ -395,6 +402,8 @@ bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *th
 bool sor_threshold_device(const float *dev_dist, size_t n, float stddev_mul, double *thr_dev);
 // Stable compaction of points with !(d_i > thr).
 std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr, const double *thr_dev = nullptr);
+// The outlier filter's last steps on the device: statistics, threshold, compaction.  Small clouds: the statistics' second kernel rides with the compaction's count.
+std::shared_ptr<DeviceSoA> sor_threshold_and_select(const DeviceSoA &src, const float *dev_dist, float stddev_mul, double *thr_dev);
 
 // Generic stable compaction driver used by tilefilter / crop / masked filter.
 // may_return_early: the call may come back with the scatter kernel still running (the result carries a

@@ -112,6 +112,7 @@ static constexpr size_t SMALL_CLOUD = 262144;
 static constexpr int SMALL_STEPS = 1;
 static constexpr int SMALL_TILE = BLOCK * ITEMS * SMALL_STEPS;
 
+size_t compact_small_cloud_limit() { return SMALL_CLOUD; }
 size_t compact_blocks(size_t n) { return n <= SMALL_CLOUD ? (n + SMALL_TILE - 1) / SMALL_TILE : (n + TILE - 1) / TILE; }
 
 struct PredArgs {
@@ -121,6 +122,10 @@ struct PredArgs {
     const float *dist;
     double thr;
     const double *thr_dev;   // mode 3: the threshold, if a kernel computed it (else thr)
+    const double *stat_partial;   // mode 3, compact_count_scan_kernel: the statistics' partial sums instead of a threshold (Predicate)
+    size_t stat_n;
+    float stat_mul;
+    double *thr_out;
 };
 
 __device__ __forceinline__ bool keep_point(const PredArgs &p, float x, float y, float z, uint32_t w, size_t idx) {
@@ -219,11 +224,49 @@ __device__ __forceinline__ uint32_t count_tile(const PredArgs &p, const float *_
     return t;   // (thread 0's value is the tile's count)
 }
 
+// The outlier filter's threshold from its 1024 pairs of partial sums (kernels_sor.hip, stats_partial_kernel): the pairwise tree and the f64
+// expressions of stats_final_kernel there, level by level in the same order, run by the BLOCK lanes of a workgroup -- every workgroup of the
+// count kernel runs it and gets the same bits; that kernel and its boundary (~5 us of a 36 k-point tile's ~90) go.
+__device__ __forceinline__ double threshold_from_partials(const double *__restrict__ partial, size_t n, float stddev_mul) {
+    constexpr int NP = 1024, PER = NP / BLOCK;
+    __shared__ double s[NP], q[NP];
+    for (int i = threadIdx.x; i < NP; i += BLOCK) { s[i] = partial[2 * i]; q[i] = partial[2 * i + 1]; }
+    __syncthreads();
+    for (unsigned width = NP / 2; width >= 1; width >>= 1) {
+        double a[PER], b[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const unsigned i = threadIdx.x + (unsigned)r * BLOCK;
+            a[r] = b[r] = 0;
+            if (i < width) { a[r] = s[2 * i] + s[2 * i + 1]; b[r] = q[2 * i] + q[2 * i + 1]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const unsigned i = threadIdx.x + (unsigned)r * BLOCK;
+            if (i < width) { s[i] = a[r]; q[i] = b[r]; }
+        }
+        __syncthreads();
+    }
+    const double sum = s[0], sq_sum = q[0];
+    const double valid = (double)n;
+    const double mean = sum / valid;
+    const double variance = (sq_sum - sum * sum / valid) / (valid - 1);
+    const double stddev = sqrt(variance);
+    return mean + (double)stddev_mul * stddev;
+}
+
 template <int S>
 __global__ void __launch_bounds__(BLOCK) compact_count_kernel(PredArgs p, const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, const uint32_t *__restrict__ rgbt, size_t n,
                                                              uint32_t *__restrict__ block_counts) {
     __shared__ uint32_t wave_sum[WAVES];
+    if (p.mode == 3 && p.stat_partial) {   // (as in compact_count_scan_kernel, should a small cloud ever come this way)
+        const double thr = threshold_from_partials(p.stat_partial, p.stat_n, p.stat_mul);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *p.thr_out = thr;
+        p.thr = thr;
+        p.thr_dev = nullptr;
+    }
     const uint32_t t = count_tile<S>(p, x, y, z, rgbt, n, wave_sum);
     if (threadIdx.x == 0) block_counts[blockIdx.x] = t;
 }
@@ -272,6 +315,12 @@ __global__ void __launch_bounds__(BLOCK) compact_count_scan_kernel(PredArgs p, c
                                                                   unsigned long long *__restrict__ total, uint32_t tag) {
     __shared__ uint32_t wave_sum[WAVES];
     __shared__ uint32_t is_last;
+    if (p.mode == 3 && p.stat_partial) {
+        const double thr = threshold_from_partials(p.stat_partial, p.stat_n, p.stat_mul);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *p.thr_out = thr;   // (the scatter kernel reads it there)
+        p.thr = thr;
+        p.thr_dev = nullptr;
+    }
     const uint32_t t = count_tile<S>(p, x, y, z, rgbt, n, wave_sum);
     if (threadIdx.x == 0) {
         __hip_atomic_store(&block_counts[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -423,6 +472,7 @@ static PredArgs to_args(const Predicate &p) {
     a.dist = p.dist;
     a.thr = p.thr;
     a.thr_dev = p.thr_dev;
+    a.stat_partial = p.stat_partial; a.stat_n = p.stat_n; a.stat_mul = p.stat_mul; a.thr_out = p.thr_out;
     return a;
 }
 

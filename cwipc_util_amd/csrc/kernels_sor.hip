@@ -234,49 +234,64 @@ __global__ void __launch_bounds__(BLK) count_nonzero_kernel(const uint32_t *__re
 // small clouds of the dense layout (a camera tile of a frame: a few ten thousand cells).  rocprim's scan runs over the whole
 // allocation (the host does not know the grid: 8 cells per point whatever the kernels made of them) in two launches, 9 + 3 us for
 // such a tile; this one reads the cell count where the grid is and takes a pass to add and a pass to write.
-constexpr int SCAN1_THREADS = 1024;
+constexpr int SCAN1_THREADS = 1024, SCAN1_PRE = 12;   // 12 groups of four cells per thread in registers: 48 k cells per round (16: spills)
+__device__ __forceinline__ uint32_t scan1_wave_inclusive(uint32_t v) {   // four DPP row shifts inside rows of 16, two row broadcasts across them
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
 __global__ void __launch_bounds__(SCAN1_THREADS) small_scan_kernel(const GridMeta *__restrict__ gm, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ counts2,
                                                                   uint32_t *__restrict__ starts, size_t cap) {
-    __shared__ uint32_t wsum[SCAN1_THREADS / 64];
+    __shared__ uint32_t wsum[2][SCAN1_THREADS / 64];
     if (counts2 && gm[1].refine) { gm += 1; counts = counts2; }   // the small clouds' flow: the coarser grid's slot and counts
     size_t ncells = grid_cells(gm->g);
     if (ncells > cap) ncells = cap;
-    // A contiguous share per thread, in whole 16-byte groups (the arrays are pool blocks, cap is a multiple of four, and what lies
-    // between the grid's last cell and the end of its group is zeroes): one pass to add the share up -- loads that do not depend on
-    // each other, all in flight together --, the scan over the threads, a second pass over the same words (they are in L2 now) to
-    // write the prefixes.  Two memory round trips and one barrier whatever the grid's size.  (First version: tiles of 16 k cells
-    // through registers, a round trip and a barrier per tile: 13 us for 35 k cells against 6 for an empty kernel of this shape; with
-    // the tile's loads under a condition the compiler made sixteen one-word loads behind branches of each: 25 us.)
-    const size_t nvec = (ncells + 3) / 4, per = (nvec + SCAN1_THREADS - 1) / SCAN1_THREADS;
-    const size_t v0 = (size_t)threadIdx.x * per < nvec ? (size_t)threadIdx.x * per : nvec, v1 = v0 + per < nvec ? v0 + per : nvec;
+    // Whole 16-byte groups (the arrays are pool blocks, cap is a multiple of four, and what lies between the grid's last cell and the end
+    // of its group is zeroes).  A round: up to twelve slices of 1024 groups, lane t of the workgroup taking group t of every slice -- every
+    // load and store instruction of a wave covers 1 KB in one piece, and all of a round's loads are in flight before the first is used --
+    // then slice by slice: the lanes' sums, a DPP scan over the wave, the waves' totals through LDS (one barrier per slice of 4096 cells).
+    // (Versions before this one, all measured on a 35 k-cell grid, where an empty kernel of this shape takes 6 us by events: a contiguous
+    // share per thread in two passes 15 us -- 144 bytes per lane apart, every wave instruction sixty-four separate requests on ONE compute
+    // unit; tiles of 16 k cells with 64 contiguous bytes per lane 13 us; with that tile's loads under a condition, which the compiler turned
+    // into sixteen one-word loads behind a branch each, 25 us.  rocprim's two launches over the whole allocation: 11.6.)
+    const size_t nvec = (ncells + 3) / 4, vlast = cap / 4 - 1;
     const uint4 *c4 = reinterpret_cast<const uint4 *>(counts);
     uint4 *s4 = reinterpret_cast<uint4 *>(starts);
-    uint32_t mine = 0;
-#pragma unroll 8
-    for (size_t v = v0; v < v1; v++) {
-        const uint4 q = c4[v];
-        mine += q.x + q.y + q.z + q.w;
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = mine;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint32_t carry = 0, flip = 0;
+    for (size_t base = 0; base < nvec; base += (size_t)SCAN1_THREADS * SCAN1_PRE) {
+        uint4 q[SCAN1_PRE];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t before = incl - mine;
+        for (int j = 0; j < SCAN1_PRE; j++) {
+            const size_t v = base + (size_t)j * SCAN1_THREADS + threadIdx.x;
+            q[j] = c4[v < vlast ? v : vlast];   // (the address clamped into the allocation, the VALUE chosen afterwards: no load under a condition)
+        }
 #pragma unroll
-    for (int w = 0; w < SCAN1_THREADS / 64; w++) {
-        const uint32_t t = wsum[w];
-        if (w < wave) before += t;
-    }
-#pragma unroll 8
-    for (size_t v = v0; v < v1; v++) {
-        const uint4 q = c4[v];
-        s4[v] = make_uint4(before, before + q.x, before + q.x + q.y, before + q.x + q.y + q.z);
-        before += q.x + q.y + q.z + q.w;
+        for (int j = 0; j < SCAN1_PRE; j++) {
+            const size_t v = base + (size_t)j * SCAN1_THREADS + threadIdx.x;
+            if (base + (size_t)j * SCAN1_THREADS >= nvec) continue;   // (the same for every lane: the barrier below is met by all or none)
+            const uint4 w = v < nvec ? q[j] : zero;
+            const uint32_t mine = w.x + w.y + w.z + w.w;
+            const uint32_t incl = scan1_wave_inclusive(mine);
+            uint32_t (&ws)[SCAN1_THREADS / 64] = wsum[flip & 1u];   // (two sets: the next slice's writers do not wait for this slice's readers)
+            flip++;
+            if (lane == 63) ws[wave] = incl;
+            __syncthreads();
+            uint32_t before = carry + incl - mine, total = 0;
+#pragma unroll
+            for (int k = 0; k < SCAN1_THREADS / 64; k++) {
+                const uint32_t t = ws[k];
+                if (k < wave) before += t;
+                total += t;
+            }
+            carry += total;
+            if (v < nvec) s4[v] = make_uint4(before, before + w.x, before + w.x + w.y, before + w.x + w.y + w.z);
+        }
     }
 }
 
@@ -774,6 +789,185 @@ __global__ void __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(KCAP <=
     dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
 }
 
+// ---- two lanes per query (r4, second session): small clouds, k = 16 ----
+// A camera tile's 36 k queries are half a wave per SIMD: the kernel lasts as long as ONE query's chain -- ~76 candidates four at a time, a sorted insert
+// for most of them -- however many queries run side by side.  Here two neighbouring lanes share a query: the same rows, the same ranges, but lane h takes
+// every second candidate (first + h, + 2, ...) into a sorted list of its own, so the chain is half as long.  What made round 3's four-lane version slower
+// (50 against 39 us) was merging the lists as sorted lists, 17 inserts per butterfly step; a query needs less:
+//   * the k + 1 nearest of the pair's candidates are, as a SET, c[j] = min(a[j], b[16 - j]) over the two sorted lists (the first step of a bitonic merge):
+//     seventeen DPP swaps and minima, and (k + 1)-th distance so far = max_j c[j] -- the bound that turns rows, rings and candidates away, refreshed
+//     after the query's own row, after the face rows and at every ring's end;
+//   * d_i = the f64 sum of the sixteen square roots in ascending order, and an f64 sum of seventeen fp32 values whose exponents lie within 2^23 of each
+//     other is EXACT in any order (every partial sum is a multiple of the smallest term's unit below 2^53 of it): the set is summed as it stands, minus
+//     the smallest term (the query itself); a query whose distances spread further (coincident points next to far ones) sorts its set first.
+// Same d_i bit for bit (the outlier tests run through this kernel for k = 16 on small clouds).  Dense layout only, k + 1 = 17.
+__device__ __forceinline__ float pair_swap(float v) {   // the other lane of the pair's value (quad_perm [1, 0, 3, 2])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
+
+__global__ void __launch_bounds__(QB) knn_pair_kernel(const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n, const uint32_t *__restrict__ cell_start,
+                                                     const uint32_t *__restrict__ cell_count, const uint32_t *__restrict__ cell_count2, float *__restrict__ dist_out) {
+    constexpr int KCAP = 17, k = 16;
+    if (cell_count2 && gm[1].refine) { gm += 1; cell_count = cell_count2; }
+    const Grid g = gm->g;
+    const size_t qi0 = ((size_t)blockIdx.x * QB + threadIdx.x) >> 1;
+    const uint32_t half = threadIdx.x & 1u;
+    const bool real = qi0 < n;
+    const size_t qi = real ? qi0 : n - 1;   // (lanes beyond the cloud run the last query along, so that every pair is whole: they write nothing)
+    const float4 q = sorted[qi];
+    const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+    float best[KCAP];
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) best[j] = INFINITY;
+    int have = 0;
+    float thr = INFINITY;   // nothing at this distance or beyond can be among the pair's k + 1 nearest
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 qxy = {q.x, q.y};
+    auto candidate = [&](const float4 p) {
+        const f32x2 dxy = qxy - f32x2{p.x, p.y};
+        const f32x2 sq = dxy * dxy;
+        const float dz = __fsub_rn(q.z, p.z);
+        const float d2 = __fadd_rn(__fadd_rn(sq.x, sq.y), __fmul_rn(dz, dz));
+        if (d2 < thr) {
+            have++;
+#pragma unroll
+            for (int j = KCAP - 1; j >= 1; j--) best[j] = __builtin_amdgcn_fmed3f(best[j - 1], best[j], d2);
+            best[0] = fminf(best[0], d2);
+            thr = fminf(thr, best[KCAP - 1]);
+        }
+    };
+    // this lane's half of a range: first + half, every second one, four loads in flight
+    auto scan = [&](uint32_t first, uint32_t last) {
+        uint32_t e = first + half;
+        for (; e + 6 < last; e += 8) {
+            const float4 p0 = sorted[e], p1 = sorted[e + 2], p2 = sorted[e + 4], p3 = sorted[e + 6];
+            candidate(p0); candidate(p1); candidate(p2); candidate(p3);
+        }
+        for (; e < last; e += 2) candidate(sorted[e]);
+    };
+    // the pair's (k + 1)-th distance so far, from the two lists
+    auto refresh = [&]() {
+        float mk = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KCAP; j++) mk = fmaxf(mk, fminf(best[j], pair_swap(best[KCAP - 1 - j])));
+        thr = fminf(thr, mk);
+    };
+    auto row_range = [&](int x0, int x1, int y, int z, uint32_t &first, uint32_t &last) {
+        const uint32_t base = (uint32_t)g.dim[0] * ((uint32_t)y + (uint32_t)g.dim[1] * (uint32_t)z);
+        const uint32_t c1 = base + (uint32_t)x1;
+        first = cell_start[base + (uint32_t)x0];
+        last = cell_start[c1] + cell_count[c1];
+    };
+    {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        uint32_t first[9], last[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+            first[r] = last[r] = 0;
+            if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) row_range(x0, x1, y, z, first[r], last[r]);
+        }
+        const float eps = (float)(g.h * 1e-5), hf = (float)g.h;
+        const float ylo = (float)((double)g.mn[1] + (double)cy * g.h), zlo = (float)((double)g.mn[2] + (double)cz * g.h);
+        auto gap = [&](float v, float lo_face, int o) {
+            const float d = o == 0 ? 0.f : (o < 0 ? v - lo_face : lo_face + hf - v);
+            const float t = fmaxf(d - eps, 0.f);
+            return t * t;
+        };
+        scan(first[4], last[4]);
+        refresh();
+        constexpr int order[8] = {1, 3, 5, 7, 0, 2, 6, 8};
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const int r = order[o];
+            if (o == 4) refresh();
+            if (gap(q.y, ylo, r % 3 - 1) + gap(q.z, zlo, r / 3 - 1) >= thr) continue;
+            scan(first[r], last[r]);
+        }
+    }
+    const int maxring = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int ring = 1; ring <= maxring; ring++) {
+        if (ring > 1) {
+            const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dim[0] - 1);
+            auto gap2 = [&](float v, int a, int cell, int o) -> float {   // (as in knn_mean_dist_reg_kernel)
+                if (o == 0) return 0.f;
+                const double face = (double)g.mn[a] + (double)(o < 0 ? cell + o + 1 : cell + o) * g.h;
+                const double d = o < 0 ? (double)v - face : face - (double)v;
+                return d > 0.0 ? (float)(d * d * (1.0 - 1e-6)) : 0.f;
+            };
+            const float gx_lo = gap2(q.x, 0, cx, -ring), gx_hi = gap2(q.x, 0, cx, ring);
+            for (int dz = -ring; dz <= ring; dz++) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.dim[2]) continue;
+                const float gz = gap2(q.z, 2, cz, dz);
+                for (int dy = -ring; dy <= ring; dy++) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.dim[1]) continue;
+                    const float gyz = gz + gap2(q.y, 1, cy, dy);
+                    if (gyz >= thr) continue;
+                    const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
+                    uint32_t first, last;
+                    if (face) {
+                        row_range(x0, x1, y, z, first, last);
+                        scan(first, last);
+                    } else {
+                        if (cx - ring >= 0 && gyz + gx_lo < thr) {
+                            row_range(cx - ring, cx - ring, y, z, first, last);
+                            scan(first, last);
+                        }
+                        if (cx + ring < g.dim[0] && gyz + gx_hi < thr) {
+                            row_range(cx + ring, cx + ring, y, z, first, last);
+                            scan(first, last);
+                        }
+                    }
+                }
+            }
+        }
+        refresh();
+        // (both lanes of a pair hold the same thr and the same sum of `have`: they leave together)
+        if (have + pair_swap_i(have) >= KCAP) {
+            const double reach = (double)ring * g.h;
+            if ((double)thr < reach * reach * (1.0 - 1e-6)) break;
+        }
+    }
+    // the pair's k + 1 nearest as a set
+    float c[KCAP];
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) c[j] = fminf(best[j], pair_swap(best[KCAP - 1 - j]));
+    float smallest = INFINITY, largest = 0.f, least = INFINITY;   // least: the smallest distance that is not zero
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) {
+        smallest = fminf(smallest, c[j]);
+        if (c[j] < INFINITY) largest = fmaxf(largest, c[j]);
+        if (c[j] > 0.f) least = fminf(least, c[j]);
+    }
+    const bool exact = !(least < INFINITY) || sqrtf(largest) < sqrtf(least) * 8388608.f;
+    double sum = 0.0;
+    if (__builtin_expect(__ballot(!exact) != 0ull, 0)) {
+        // distances spread over more than 2^23: the order of the sum may matter -- ascending, as the reference has it
+        float srt[KCAP];
+#pragma unroll
+        for (int j = 0; j < KCAP; j++) srt[j] = INFINITY;
+#pragma unroll 1
+        for (int i = 0; i < KCAP; i++) {
+            float v = c[0];
+#pragma unroll
+            for (int j = 1; j < KCAP; j++) v = i == j ? c[j] : v;
+#pragma unroll
+            for (int j = KCAP - 1; j >= 1; j--) srt[j] = __builtin_amdgcn_fmed3f(srt[j - 1], srt[j], v);
+            srt[0] = fminf(srt[0], v);
+        }
+#pragma unroll
+        for (int j = 1; j < KCAP; j++) if (srt[j] < INFINITY) sum += (double)sqrtf(srt[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < KCAP; j++) if (c[j] < INFINITY) sum += (double)sqrtf(c[j]);
+        if (smallest < INFINITY) sum -= (double)sqrtf(smallest);
+    }
+    if (real && half == 0u) dist_out[__float_as_uint(q.w)] = (float)(sum / (double)k);
+}
+
 // (Round 4, built, measured and taken out again -- the commit before this comment's has the kernels, profiles/r04_sor_knn_staged.txt the figures:
 // the neighbourhood of 64 consecutive sorted points staged in LDS by the whole wave -- the nine runs of cells [ca - 1, cb + 1] shifted by the row
 // offsets, one round trip -- and every lane scanning its own three cells of each row there; before it, a wave per row of cells.  d_i bit-identical;
@@ -913,7 +1107,10 @@ bool sor_small_on_device(const DeviceSoA &src, int k, float *dev_dist, size_t ca
     CW_LAUNCH("sor_exclusive_scan", small_scan_kernel, dim3(1), dim3(SCAN1_THREADS), 0, c.stream, meta, counts, counts2, starts, cap);
     CW_LAUNCH("sor_cell_scatter", cell_scatter_kernel, dim3(pgrid), dim3(BLK), 0, c.stream, src.x(), src.y(), src.z(), n, cell_id, starts, cursor, sorted);
     const unsigned qgrid = (unsigned)((n + QB - 1) / QB);
-    if (k + 1 <= 17) {
+    static const bool pair_off = []() { const char *e = getenv("CWIPC_SOR_PAIR"); return e && atoi(e) == 0; }();   // test knob: a lane per query
+    if (k == 16 && !pair_off) {
+        CW_LAUNCH("sor_knn_mean_dist", knn_pair_kernel, dim3((unsigned)((2 * n + QB - 1) / QB)), dim3(QB), 0, c.stream, meta, sorted, n, starts, counts, counts2, dev_dist);
+    } else if (k + 1 <= 17) {
         CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<17, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist, counts2);
     } else {
         CW_LAUNCH("sor_knn_mean_dist", (knn_mean_dist_reg_kernel<33, false>), dim3(qgrid), dim3(QB), 0, c.stream, unused, meta, sorted, n, starts, counts, k, dev_dist, counts2);
@@ -1239,6 +1436,30 @@ bool sor_threshold(const float *dev_dist, size_t n, float stddev_mul, double *th
     double stddev = sqrt(variance);
     *thr = mean + (double)stddev_mul * stddev;
     return true;
+}
+
+std::shared_ptr<DeviceSoA> sor_threshold_and_select(const DeviceSoA &src, const float *dev_dist, float stddev_mul, double *thr_dev) {
+    const size_t n = src.npoints;
+    static const bool fold_off = []() { const char *e = getenv("CWIPC_SOR_STATS_FOLD"); return e && atoi(e) == 0; }();   // test knob: the statistics' second kernel on its own
+    if (n > k::compact_small_cloud_limit() || fold_off) {
+        if (!sor_threshold_device(dev_dist, n, stddev_mul, thr_dev)) return nullptr;
+        return sor_select(src, dev_dist, 0.0, thr_dev);
+    }
+    // small clouds: the partial sums only; the compaction's count kernel turns them into the threshold (kernels_basic.hip, threshold_from_partials)
+    ThreadCtx &c = tctx();
+    if (!c.ensure()) return nullptr;
+    const unsigned nb = 1024;
+    double *partial = (double *)pool_alloc(nb * 2 * sizeof(double));
+    if (!partial) return nullptr;
+    CW_LAUNCH("sor_stats", stats_partial_kernel, dim3(nb), dim3(BLK), 0, c.stream, dev_dist, n, partial);
+    k::Predicate p{};
+    p.mode = 3;
+    p.dist = dev_dist;
+    p.thr_dev = thr_dev;
+    p.stat_partial = partial; p.stat_n = n; p.stat_mul = stddev_mul; p.thr_out = thr_dev;
+    auto out = compact(src, p);   // (waits for its kernels)
+    c.free_later(partial);
+    return out;
 }
 
 std::shared_ptr<DeviceSoA> sor_select(const DeviceSoA &src, const float *dev_dist, double thr, const double *thr_dev) {

@@ -1094,7 +1094,7 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
 
 
 @pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0",
-                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4", "CWIPC_SOR_SMALL_CELLS=0"])   # (+ CWIPC_PINNED_UPLOAD=kernel: test_page_locked_buffers_both_ways)
+                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4", "CWIPC_SOR_SMALL_CELLS=0", "CWIPC_SOR_PAIR=0"])   # (+ CWIPC_PINNED_UPLOAD=kernel: test_page_locked_buffers_both_ways)
 def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
     """Every environment knob of the shipped library selects another way to the same result: a
     process with the knob set must produce, bit for bit, what this process produces -- a stream of downsample calls (the
@@ -1303,6 +1303,49 @@ def test_remove_outliers_tiny_clouds(gpu, oracle):
         pts['x'] = np.arange(n) * 0.1
         got = gpu.cwipc_remove_outliers(make_cloud(gpu, pts), 16, 1.0, False).get_numpy_array()
         assert same(got, oracle.remove_outliers(pts, 16, 1.0, False)), n
+
+
+@pytest.mark.parametrize("n", [65535, 65536, 65537, 150000])
+@pytest.mark.parametrize("kind", ["sheet", "box", "edge"])
+def test_remove_outliers_either_side_of_the_small_flow(gpu, oracle, n, kind):
+    """Clouds up to 65 536 points (8 cells per point = 2^19 cells) take the ten-launch flow of round 4 (kernels_sor.hip,
+    sor_small_on_device: the grid derived by every workgroup of the count kernels, a one-workgroup scan), bigger ones the twelve-launch
+    flow; both search with the k-NN kernel whose shells beyond the first are bounded row by row.  d_i bit for bit on both sides of the
+    line: a sheet (the grid is coarsened after the census), a box (it is not: ~1 point per cell of the finest grid is already volume-like),
+    and a thin strip whose every query is an edge query (second and third shells)."""
+    if kind == "box" and n not in (65536, 65537):
+        pytest.skip("the oracle's search through a volume takes ten seconds and more at these sizes: the two sizes at the line only")
+    rng = np.random.default_rng(n + len(kind))
+    if kind == "sheet":
+        xyz = np.stack([rng.random(n) * 2.0, rng.random(n) * 1.0, 0.05 * np.sin(rng.random(n) * 6.0)], axis=1)
+    elif kind == "box":
+        xyz = rng.random((n, 3)) * 1.5
+    else:
+        xyz = np.stack([rng.random(n) * 40.0, rng.random(n) * 0.01, np.zeros(n)], axis=1)
+    pts = oracle.empty(n)
+    pts['x'], pts['y'], pts['z'] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    for k in ((16,) if kind == "box" else (16, 30)):
+        d_got, _ = gpu.cwipc_hip_knn_mean_dist(make_cloud(gpu, pts), k, 1.0)
+        d_exp = oracle.knn_mean_dist(pts, k)
+        assert (d_got == d_exp).all(), (n, kind, k, np.flatnonzero(d_got != d_exp)[:5])
+
+
+def test_remove_outliers_distances_spread_over_many_binades(gpu, oracle):
+    """The two-lanes-per-query k-NN kernel (small clouds, k = 16) sums a query's sixteen distances as a set, which is exact in f64 in any
+    order while they lie within 2^23 of each other; a query whose neighbours are partly a nanometre and partly a centimetre away takes the
+    sorted sum.  Both give the oracle's d_i bit for bit."""
+    rng = np.random.default_rng(77)
+    centres = np.array([[i, j, l] for i in range(2) for j in range(2) for l in range(3)], dtype=np.float64) * 0.01
+    xyz = (centres[:, None, :] + rng.random((len(centres), 10, 3)) * 3e-9).reshape(-1, 3)
+    xyz = np.concatenate([xyz, rng.random((400, 3)) * 0.02 + 0.05])   # ... next to ordinary queries in the same waves
+    pts = oracle.empty(len(xyz))
+    pts['x'], pts['y'], pts['z'] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    d_exp = oracle.knn_mean_dist(pts, 16)
+    near = np.sort(np.linalg.norm(xyz[:1] - xyz[1:10], axis=1))
+    assert near[0] > 0 and 0.009 / near[0] > 2 ** 23      # the case is what it says
+    d_got, _ = gpu.cwipc_hip_knn_mean_dist(make_cloud(gpu, pts), 16, 1.0)
+    assert (d_got == d_exp).all(), np.flatnonzero(d_got != d_exp)[:5]
+    check_sor(gpu, oracle, pts, 0.001, 16, 1.0)
 
 
 @pytest.mark.parametrize("seed", range(40))
