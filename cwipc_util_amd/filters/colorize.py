@@ -22,25 +22,33 @@ class ColorMap:
 
     def __init__(self, initializer: Optional[Dict[int, ColorTuple]] = None):
         self._map: List[Optional[ColorTuple]] = [None] * 256
+        self._tables: Optional[Tuple[numpy.ndarray, numpy.ndarray]] = None   # what tables() made of the map as it stands
         if initializer:
             for k, v in initializer.items():
                 self._map[k] = v
 
     def add_mapping(self, tilenum: int, color: ColorTuple) -> None:
         self._map[tilenum] = color
+        self._tables = None
 
     def map(self, tilenum: int) -> Optional[ColorTuple]:
         return self._map[tilenum]
 
     def tables(self) -> Tuple[numpy.ndarray, numpy.ndarray]:
-        """(lut (256,3) float64, valid (256,) uint8) -- the form the C entry point takes."""
+        """(lut (256,3) float64, valid (256,) uint8) -- the form the C entry point takes.  Made once per state of the map: a filter
+        colours every tile of every frame with the same map, and the loop below was a third of a call on a camera tile."""
+        if self._tables is not None:
+            return self._tables
         lut = numpy.zeros((256, 3), dtype=numpy.float64)
         valid = numpy.zeros(256, dtype=numpy.uint8)
         for t, c in enumerate(self._map):
             if c is not None:
                 lut[t] = [float(c[0]), float(c[1]), float(c[2])]
                 valid[t] = 1
-        return lut, valid
+        lut.setflags(write=False)
+        valid.setflags(write=False)
+        self._tables = (lut, valid)
+        return self._tables
 
 
 # reference colorize.py:21-29 -- one colour per single-camera tile number
