@@ -1094,7 +1094,7 @@ def test_fast_and_general_accumulate_kernels_agree(gpu, synth):
 
 
 @pytest.mark.parametrize("knob", ["CWIPC_DEFER=0", "CWIPC_VOXEL_PARTITION=0", "CWIPC_SOR_HOST_GRID=1", "CWIPC_SYNTHETIC_HOST=1", "CWIPC_POLL_US=0",
-                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4", "CWIPC_SOR_SMALL_CELLS=0", "CWIPC_SOR_PAIR=0"])   # (+ CWIPC_PINNED_UPLOAD=kernel: test_page_locked_buffers_both_ways)
+                                  "CWIPC_K1_DUMP=1", "CWIPC_K1_DUMP=2", "CWIPC_K1_PAIR=1", "CWIPC_WORKSPACES=1", "CWIPC_WORKSPACES=4", "CWIPC_SOR_SMALL_CELLS=0", "CWIPC_SOR_PAIR=0", "CWIPC_SOR_STATS_FOLD=0"])   # (+ CWIPC_PINNED_UPLOAD=kernel: test_page_locked_buffers_both_ways)
 def test_variant_knobs_change_no_result(gpu, synth, knob, tmp_path):
     """Every environment knob of the shipped library selects another way to the same result: a
     process with the knob set must produce, bit for bit, what this process produces -- a stream of downsample calls (the
