@@ -638,8 +638,12 @@ bool launch_knn_list(const Grid &gv, const GridMeta *gm, const float4 *sorted, s
 // so the largest kept distance is always the last register.
 // SPARSE: cell_start is indexed by the cells that exist (one entry more than there are cells: the end), cell_count is the
 // segment table (seg_pack_kernel).
+// (r4, second session: six waves per SIMD for k <= 16 -- 80 registers, eight of them spilled, and still 6 % faster at 10 M points than five waves without
+// a spill: the counters put 54 % of a wave's cycles there into waiting for its loads (SQ_WAIT_ANY; 249 loads, 5300 vector instructions per wave), and what
+// hides a wait is another wave.  Eight waves (44 spilled) give it back; requesting the next four candidates before looking at these four changed nothing at
+// five waves and cost 8 % at four.  profiles/r04_sor_knn_10m.txt)
 template <int KCAP, bool SPARSE>
-__global__ void __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(KCAP <= 17 ? 5 : 4))) knn_mean_dist_reg_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
+__global__ void __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(KCAP <= 17 ? 6 : 4))) knn_mean_dist_reg_kernel(Grid gv, const GridMeta *__restrict__ gm, const float4 *__restrict__ sorted, size_t n,
                                                               const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_count, int k,
                                                               float *__restrict__ dist_out, const uint32_t *__restrict__ cell_count2 = nullptr) {
     if (cell_count2 && gm[1].refine) { gm += 1; cell_count = cell_count2; }   // the small clouds' flow: the coarser grid's slot and counts
