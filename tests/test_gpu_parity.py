@@ -1330,6 +1330,33 @@ def test_remove_outliers_either_side_of_the_small_flow(gpu, oracle, n, kind):
         assert (d_got == d_exp).all(), (n, kind, k, np.flatnonzero(d_got != d_exp)[:5])
 
 
+@pytest.mark.parametrize("kind", ["dupes", "line", "clusters", "few", "lattice"])
+def test_remove_outliers_two_lanes_per_query_shapes(gpu, oracle, kind):
+    """k = 16 on small clouds runs the k-NN kernel with two lanes per query (each lane every second candidate, the pair's nearest as a set):
+    shapes that stress what is special about it -- more coincident points than neighbours (every distance zero, nothing to tell the smallest
+    by), all candidates in one row of cells (a line), lists that never fill (fewer points than k + 1 in reach), ties at the (k + 1)-th
+    distance (a lattice: rows and rings are turned away on equal bounds) -- against the oracle's d_i, bit for bit."""
+    rng = np.random.default_rng(len(kind) * 7 + 1)
+    if kind == "dupes":
+        base = rng.random((40, 3))
+        xyz = base[rng.integers(0, 40, 3000)]                     # ~75 copies of each of 40 places
+    elif kind == "line":
+        xyz = np.stack([rng.random(5000) * 3.0, np.full(5000, 0.5), np.full(5000, -0.25)], axis=1)
+    elif kind == "clusters":
+        centres = rng.random((7, 3)) * 4.0
+        xyz = centres[rng.integers(0, 7, 6000)] + rng.normal(0, 0.002, (6000, 3))
+    elif kind == "few":
+        xyz = rng.random((19, 3))
+    else:
+        g = np.arange(18, dtype=np.float64) * 0.125               # exactly representable: many equal distances
+        xyz = np.stack(np.meshgrid(g, g, g[:9], indexing="ij"), axis=-1).reshape(-1, 3)
+    pts = oracle.empty(len(xyz))
+    pts['x'], pts['y'], pts['z'] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    d_got, _ = gpu.cwipc_hip_knn_mean_dist(make_cloud(gpu, pts), 16, 1.0)
+    d_exp = oracle.knn_mean_dist(pts, 16)
+    assert (d_got == d_exp).all(), (kind, np.flatnonzero(d_got != d_exp)[:5])
+
+
 def test_remove_outliers_distances_spread_over_many_binades(gpu, oracle):
     """The two-lanes-per-query k-NN kernel (small clouds, k = 16) sums a query's sixteen distances as a set, which is exact in f64 in any
     order while they lie within 2^23 of each other; a query whose neighbours are partly a nanometre and partly a centimetre away takes the
