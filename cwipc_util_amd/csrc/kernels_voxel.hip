@@ -313,6 +313,26 @@ __device__ __forceinline__ uint32_t leaf_lookup(const VoxWork &W, uint32_t mask,
     return 0xffffffffu;
 }
 
+// The same question asked through the caches first (r4, second session; the fast accumulate kernel's flush).  An entry of the leaf table never
+// changes once its id is published, and this XCD's L2 holds nothing older than the kernel's start: a plain load that shows the key WITH its id
+// shows the truth, and one that does not (an empty slot, a key without its id, a line that went into L2 before the leaf was claimed) sends the lane
+// to leaf_lookup's loads at device scope.  Those go past the L2 to the memory side, where the lookups of ALL workgroups -- a cloud has a dozen
+// leaves, a 300 k-point cloud 234 workgroups that flush at the same moment -- queue at a dozen addresses: 1.2 to 13 us per lookup by the time stamps.
+__device__ __forceinline__ uint32_t leaf_lookup_cached(const VoxWork &W, uint32_t mask, unsigned long long k) {
+    uint32_t pos = (uint32_t)mix64(k) & mask;
+    for (uint32_t probes = 0; probes < 8u; probes++) {
+        const unsigned long long cur = __hip_atomic_load(&W.hash_keys[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (cur == k) {
+            const uint32_t v = __hip_atomic_load(&W.hash_ids[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (v != 0u && v != 0xffffffffu) return v - 1u;
+            break;
+        }
+        if (cur == 0ull) break;
+        pos = (pos + 1) & mask;
+    }
+    return leaf_lookup(W, mask, k);
+}
+
 // Record of voxel key = leaf id << 19 | cell  (grids are CELLS records apart, not 2^19).
 __device__ __forceinline__ unsigned long long *record_ptr(const VoxWork &W, uint32_t key) {
     return W.records + ((size_t)(key >> CELL_BITS) * CELLS + (key & ((1u << CELL_BITS) - 1))) * RECORD_WORDS;
