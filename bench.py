@@ -608,10 +608,18 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Setup, whatever W is (r4): a thread whose downsample calls come back to back takes a second and a third voxel workspace (0.3 GB
+    # of leaf grids each, ~10 ms of allocation), and it takes them when a call finds the workspace whose turn it is still at work --
+    # somewhere in the first ten or twenty calls of a stream.  With a short warm-up that was inside the timed region (W = 10, K = 50:
+    # 177 us per step instead of 47).  A burst of calls nobody waits for, before the warm-up steps: allocation is setup, not a step.
+    for burst in range(3):
+        held = [cwipc.cwipc_downsample(clouds[i % NCOPIES], CELLSIZE) for i in range(12)]
+        held[-1].count()
+        del held
     for i in range(args.warmup):
         step(i)
-    # output points of this rank's own tile; four calls, so that both of the library's per-thread workspaces (used by
-    # alternate calls, 1.3 GB each) exist and know the size of their results whatever W is -- allocation is setup
+    # output points of this rank's own tile; four calls, so that the library's per-thread workspaces know the size of their results
+    # whatever W is
     for _ in range(4):
         n_out = cwipc.cwipc_downsample(clouds[0], CELLSIZE).count()
 
